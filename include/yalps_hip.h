@@ -1,0 +1,118 @@
+/*
+ * yalps_hip.h -- C ABI of the MI355X (gfx950) dense-tableau simplex core.
+ *
+ * This is the drop-in boundary for ONE hot path of Ivordir/YALPS: the ES-module
+ * export `simplex` (reference src/simplex.ts:144; called at src/YALPS.ts:79 and
+ * src/branchAndCut.ts:127).  The reference has no FFI of its own; the entry
+ * points below are exactly what an N-API / ctypes binding of that export needs
+ * (INTEGRATION.md shows the stub).  Plain pointers and sizes only.
+ *
+ * Data layout at the boundary = reference src/tableau.ts:9-21: `matrix` is a
+ * row-major Float64Array of width*height doubles, row 0 = objective row,
+ * column 0 = RHS column; `positionOfVariable` / `variableAtPosition` are Int32
+ * arrays of width+height entries.  Everything is mutated in place exactly as
+ * src/simplex.ts does.
+ *
+ * Return protocol (src/simplex.ts:66-69,80,96,98,102,120,135,137,141):
+ *   return value >= 0 : SolutionStatus code below; *result_out = rounded M[0,0]
+ *                       (optimal) | entering column index (unbounded) | NaN.
+ *   return value <  0 : native failure (HIP error, OOM, bad argument) -- the
+ *                       reference never throws on this path, so this is the
+ *                       out-of-band channel; text via yalps_last_error().
+ * There is NO CPU fallback: without a usable gfx950 device every entry point
+ * fails with YALPS_E_DEVICE.
+ */
+#ifndef YALPS_HIP_H
+#define YALPS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* SolutionStatus codes produced by the hot path (src/types.ts SolutionStatus;
+ * "timedout" is produced only by branch-and-cut, never by simplex()). */
+#define YALPS_OPTIMAL 0
+#define YALPS_INFEASIBLE 1
+#define YALPS_UNBOUNDED 2
+#define YALPS_CYCLED 3
+
+#define YALPS_E_ARG (-1)    /* bad argument */
+#define YALPS_E_DEVICE (-2) /* no usable HIP device / HIP runtime error */
+#define YALPS_E_NOMEM (-3)  /* device or host allocation failed */
+
+/* What yalps_simplex_f64_ex copies back to the caller's arrays. */
+#define YALPS_COPYBACK_FULL 0     /* whole matrix + both permutations (reference semantics) */
+#define YALPS_COPYBACK_SOLUTION 1 /* column 0 (strided into matrix) + both permutations: all that
+                                     solution() reads for a pure LP (src/YALPS.ts:18-19,32) */
+
+const char *yalps_last_error(void);
+int32_t yalps_device_count(void);
+
+/* ---- the drop-in: replaces `simplex(tableau, options)` (src/simplex.ts:106-144) -------------
+ * Host arrays in, host arrays out, synchronous, non-re-entrant (like the single JS thread).
+ * Options read on this path: precision, maxPivots (may be +Infinity), checkCycles
+ * (src/simplex.ts:68,108).  The arrays are not retained after return. */
+int32_t yalps_simplex_f64(double *matrix, int32_t width, int32_t height, int32_t *positionOfVariable,
+                          int32_t *variableAtPosition, double precision, double maxPivots,
+                          int32_t checkCycles, double *result_out);
+
+int32_t yalps_simplex_f64_ex(double *matrix, int32_t width, int32_t height,
+                             int32_t *positionOfVariable, int32_t *variableAtPosition,
+                             double precision, double maxPivots, int32_t checkCycles,
+                             int32_t copyback, double *result_out, int64_t *pivots_out);
+
+/* ---- device-resident tableaux (HBM) -------------------------------------------------------
+ * For callers that keep the tableau on the GPU between calls (benchmarks, branch-and-cut node
+ * evaluation: src/branchAndCut.ts:126-127 re-solves root+cuts per node). */
+typedef struct yalps_ctx yalps_ctx;
+typedef struct yalps_tableau yalps_tableau;
+
+int32_t yalps_ctx_create(int32_t device, yalps_ctx **out);
+void yalps_ctx_destroy(yalps_ctx *ctx);
+
+/* A tableau of `width` columns and room for up to `height_capacity` rows. */
+int32_t yalps_tableau_create(yalps_ctx *ctx, int32_t width, int32_t height_capacity,
+                             yalps_tableau **out);
+void yalps_tableau_destroy(yalps_tableau *t);
+
+/* Host -> HBM: row-major width*height doubles + the two permutations (width+height int32). */
+int32_t yalps_tableau_upload(yalps_tableau *t, const double *matrix, int32_t height,
+                             const int32_t *positionOfVariable, const int32_t *variableAtPosition);
+/* HBM -> host; any of the three pointers may be NULL to skip it. */
+int32_t yalps_tableau_download(yalps_tableau *t, double *matrix, int32_t *positionOfVariable,
+                               int32_t *variableAtPosition);
+/* HBM -> host, only column 0 (height doubles, contiguous). */
+int32_t yalps_tableau_download_rhs(yalps_tableau *t, double *col0);
+/* HBM -> HBM copy of matrix + permutations + height (same width; dst capacity >= src height). */
+int32_t yalps_tableau_copy(yalps_tableau *dst, const yalps_tableau *src);
+int32_t yalps_tableau_height(const yalps_tableau *t);
+
+/* Run the two-phase simplex on the resident tableau (in place).  gpu_ms_out (optional) =
+ * HIP-event time of the whole pivot loop on the context's stream. */
+int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots,
+                            int32_t checkCycles, double *result_out, int64_t *pivots_out,
+                            float *gpu_ms_out);
+
+/* One bare Gauss-Jordan pivot (src/simplex.ts:5-39) on the resident tableau. */
+int32_t yalps_tableau_pivot(yalps_tableau *t, int32_t row, int32_t col);
+
+/* Measurement hook: `launches` back-to-back launches of the row-elimination sweep kernel alone
+ * (pivot (row,col) re-applied each time; the tableau content is consumed), timed with HIP
+ * events on the context's stream.  *avg_us_out = average kernel duration. */
+int32_t yalps_tableau_bench_sweep(yalps_tableau *t, int32_t row, int32_t col, int32_t launches,
+                                  float *avg_us_out);
+
+/* ---- synthetic input of the headline benchmark ---------------------------------------------
+ * dense-LP(M,N,seed): fills a (M+1) x (N+1) row-major tableau with the
+ * reference test-suite's PRNG stream (tests/helpers/util.ts:20-41).  Host-side, deterministic. */
+void yalps_dense_lp_f64(int32_t M, int32_t N, double seed, double *matrix);
+
+/* JS-exact roundToPrecision (src/util.ts:1-4), for host marshalling code. */
+double yalps_round_to_precision(double num, double precision);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YALPS_HIP_H */

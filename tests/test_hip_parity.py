@@ -1,0 +1,125 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against (a) the committed
+golden records produced by the reference's own src/simplex.ts and (b) the CPU oracle on seeded
+inputs.  Bit-exact: status, result, pivot count, permutations, RHS column, whole matrix."""
+import numpy as np
+import pytest
+
+from tests import _golden as G
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from yalps_amd import _native
+    assert _native.lib().yalps_device_count() >= 1, "no HIP device: the GPU tests need a real MI355X"
+    return _native
+
+
+@pytest.fixture(scope="module")
+def ctx(nat):
+    c = nat.Context(0)
+    yield c
+    c.close()
+
+
+GOLDEN = [pytest.param(r, id=G.label(r)) for kind in ("cases", "mixed", "dense") for r in G.records(kind)]
+
+
+@pytest.mark.parametrize("rec", GOLDEN)
+def test_dropin_matches_reference_golden(nat, oracle, rec):
+    """yalps_simplex_f64 (host arrays in/out) == reference simplex() on every golden record."""
+    m = G.initial_matrix(rec, oracle, dense_gen=nat.dense_lp)
+    pos, var = G.identity_perms(rec)
+    exp = G.expected(rec)
+    status, result, npiv = nat.simplex_host(m, rec["width"], rec["height"], pos, var, **G.options(rec))
+    assert status == exp["status"]
+    assert G.same_number(result, exp["result"])
+    assert npiv == exp["n_pivots"]
+    assert np.array_equal(pos, exp["pos"]) and np.array_equal(var, exp["var"])
+    col0 = m.reshape(rec["height"], rec["width"])[:, 0]
+    assert np.array_equal(col0.view(np.int64), exp["col0"].view(np.int64))
+    assert G.sha256(m) == exp["final_sha256"]
+
+
+def test_dense_generator_matches_oracle(nat, oracle):
+    for M, N, seed in ((3, 5, 42), (64, 64, 7), (300, 200, 1)):
+        assert np.array_equal(nat.dense_lp(M, N, seed), oracle.dense_lp(M, N, seed))
+
+
+@pytest.mark.parametrize("shape", [(4, 3), (17, 130), (200, 513), (513, 200), (700, 1100)])
+def test_single_pivot_matches_oracle(nat, ctx, oracle, shape):
+    """One bare Gauss-Jordan pivot (src/simplex.ts:5-39) on random data with exact zeros and
+    entries around the 1e-16 flush / skip threshold."""
+    h, w = shape
+    rng = np.random.default_rng(h * 1000 + w)
+    m = rng.uniform(-1, 1, h * w)
+    m[rng.random(h * w) < 0.3] = 0.0
+    tiny = rng.random(h * w) < 0.05
+    m[tiny] = rng.uniform(-2e-16, 2e-16, tiny.sum())
+    m[rng.random(h * w) < 0.01] = -0.0
+    row, col = int(rng.integers(1, h)), int(rng.integers(1, w))
+    m[row * w + col] = 0.37
+    pos = np.arange(w + h, dtype=np.int32)
+    var = np.arange(w + h, dtype=np.int32)
+    ref, rpos, rvar = m.copy(), pos.copy(), var.copy()
+    oracle.pivot(ref, w, h, rpos, rvar, row, col)
+    t = nat.DeviceTableau(ctx, w, h)
+    try:
+        t.upload(m, h, pos, var)
+        t.pivot(row, col)
+        got, gpos, gvar = t.download()
+    finally:
+        t.close()
+    assert np.array_equal(got.view(np.int64), ref.view(np.int64))
+    assert np.array_equal(gpos, rpos) and np.array_equal(gvar, rvar)
+
+
+@pytest.mark.parametrize("M,N,seed", [(300, 300, 5), (150, 700, 11), (900, 400, 3)])
+def test_device_solve_matches_oracle_dense(nat, ctx, oracle, M, N, seed):
+    w, h = N + 1, M + 1
+    m = nat.dense_lp(M, N, seed)
+    pos = np.arange(w + h, dtype=np.int32)
+    var = np.arange(w + h, dtype=np.int32)
+    ref, rpos, rvar = m.copy(), pos.copy(), var.copy()
+    est, eres, epiv, _ = oracle.simplex(ref, w, h, rpos, rvar, max_pivots=np.inf)
+    t = nat.DeviceTableau(ctx, w, h)
+    try:
+        t.upload(m, h, pos, var)
+        status, result, npiv, ms = t.solve(max_pivots=np.inf)
+        got, gpos, gvar = t.download()
+        rhs = t.download_rhs()
+    finally:
+        t.close()
+    assert (status, npiv) == (est, epiv) and G.same_number(result, eres)
+    assert np.array_equal(got.view(np.int64), ref.view(np.int64))
+    assert np.array_equal(rhs.view(np.int64), ref.reshape(h, w)[:, 0].view(np.int64))
+    assert np.array_equal(gpos, rpos) and np.array_equal(gvar, rvar)
+
+
+def test_copyback_solution_only(nat, oracle):
+    rec = next(r for r in G.records("dense") if r["M"] == 128)
+    m = G.initial_matrix(rec, oracle, dense_gen=nat.dense_lp)
+    init = m.copy()
+    pos, var = G.identity_perms(rec)
+    exp = G.expected(rec)
+    status, result, npiv = nat.simplex_host(m, rec["width"], rec["height"], pos, var, copyback=nat.COPYBACK_SOLUTION,
+                                            **G.options(rec))
+    assert status == exp["status"] and result == exp["result"]
+    mm = m.reshape(rec["height"], rec["width"])
+    assert np.array_equal(mm[:, 0].view(np.int64), exp["col0"].view(np.int64))
+    assert np.array_equal(mm[:, 1:], init.reshape(mm.shape)[:, 1:])  # untouched on the host
+    assert np.array_equal(pos, exp["pos"]) and np.array_equal(var, exp["var"])
+
+
+def test_bad_arguments_fail_loudly(nat, ctx):
+    with pytest.raises(nat.NativeError):
+        nat.DeviceTableau(ctx, 0, 4)
+    t = nat.DeviceTableau(ctx, 4, 4)
+    try:
+        with pytest.raises(nat.NativeError):
+            t.solve()  # nothing uploaded
+        with pytest.raises(nat.NativeError):
+            t.upload(np.zeros(4 * 9), 9, np.arange(13, dtype=np.int32), np.arange(13, dtype=np.int32))
+    finally:
+        t.close()

@@ -1,0 +1,180 @@
+"""ctypes binding of libyalps_hip.so (include/yalps_hip.h).
+
+There is no CPU path: if the library is missing, or no gfx950 device is usable,
+every call raises.  Nothing here imports the oracle.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libyalps_hip.so")
+
+STATUS = ("optimal", "infeasible", "unbounded", "cycled")
+COPYBACK_FULL, COPYBACK_SOLUTION = 0, 1
+
+# every symbol include/yalps_hip.h declares
+SYMBOLS = (
+    "yalps_last_error", "yalps_device_count", "yalps_simplex_f64", "yalps_simplex_f64_ex", "yalps_ctx_create",
+    "yalps_ctx_destroy", "yalps_tableau_create", "yalps_tableau_destroy", "yalps_tableau_upload",
+    "yalps_tableau_download", "yalps_tableau_download_rhs", "yalps_tableau_copy", "yalps_tableau_height",
+    "yalps_tableau_solve", "yalps_tableau_pivot", "yalps_tableau_bench_sweep", "yalps_dense_lp_f64",
+    "yalps_round_to_precision",
+)
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        f64p, i32p, vp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_void_p
+        L.yalps_last_error.restype = C.c_char_p
+        L.yalps_device_count.restype = C.c_int32
+        L.yalps_simplex_f64.restype = C.c_int32
+        L.yalps_simplex_f64.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, C.c_double, C.c_double, C.c_int32, f64p]
+        L.yalps_simplex_f64_ex.restype = C.c_int32
+        L.yalps_simplex_f64_ex.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, C.c_double, C.c_double, C.c_int32,
+                                           C.c_int32, f64p, C.POINTER(C.c_int64)]
+        L.yalps_ctx_create.restype = C.c_int32
+        L.yalps_ctx_create.argtypes = [C.c_int32, C.POINTER(vp)]
+        L.yalps_ctx_destroy.restype = None
+        L.yalps_ctx_destroy.argtypes = [vp]
+        L.yalps_tableau_create.restype = C.c_int32
+        L.yalps_tableau_create.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(vp)]
+        L.yalps_tableau_destroy.restype = None
+        L.yalps_tableau_destroy.argtypes = [vp]
+        L.yalps_tableau_upload.restype = C.c_int32
+        L.yalps_tableau_upload.argtypes = [vp, vp, C.c_int32, vp, vp]
+        L.yalps_tableau_download.restype = C.c_int32
+        L.yalps_tableau_download.argtypes = [vp, vp, vp, vp]
+        L.yalps_tableau_download_rhs.restype = C.c_int32
+        L.yalps_tableau_download_rhs.argtypes = [vp, vp]
+        L.yalps_tableau_copy.restype = C.c_int32
+        L.yalps_tableau_copy.argtypes = [vp, vp]
+        L.yalps_tableau_height.restype = C.c_int32
+        L.yalps_tableau_height.argtypes = [vp]
+        L.yalps_tableau_solve.restype = C.c_int32
+        L.yalps_tableau_solve.argtypes = [vp, C.c_double, C.c_double, C.c_int32, f64p, C.POINTER(C.c_int64),
+                                          C.POINTER(C.c_float)]
+        L.yalps_tableau_pivot.restype = C.c_int32
+        L.yalps_tableau_pivot.argtypes = [vp, C.c_int32, C.c_int32]
+        L.yalps_tableau_bench_sweep.restype = C.c_int32
+        L.yalps_tableau_bench_sweep.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float)]
+        L.yalps_dense_lp_f64.restype = None
+        L.yalps_dense_lp_f64.argtypes = [C.c_int32, C.c_int32, C.c_double, vp]
+        L.yalps_round_to_precision.restype = C.c_double
+        L.yalps_round_to_precision.argtypes = [C.c_double, C.c_double]
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc < 0:
+        raise NativeError("yalps_hip error %d: %s" % (rc, lib().yalps_last_error().decode()))
+    return rc
+
+
+def _ptr(a, dtype):
+    if a is None:
+        return None
+    assert isinstance(a, np.ndarray) and a.dtype == dtype and a.flags.c_contiguous, (type(a), getattr(a, "dtype", None))
+    return a.ctypes.data
+
+
+def simplex_host(matrix, width, height, pos, var, precision=1e-8, max_pivots=8192.0, check_cycles=False,
+                 copyback=COPYBACK_FULL):
+    """The drop-in: in-place on host numpy arrays, like the reference's simplex(tableau, options).
+    Returns (status, result, n_pivots)."""
+    assert matrix.size >= width * height
+    res, npiv = C.c_double(), C.c_int64()
+    st = check(lib().yalps_simplex_f64_ex(_ptr(matrix, np.float64), width, height, _ptr(pos, np.int32),
+                                          _ptr(var, np.int32), precision, float(max_pivots), int(bool(check_cycles)),
+                                          copyback, C.byref(res), C.byref(npiv)))
+    return STATUS[st], res.value, npiv.value
+
+
+class Context:
+    def __init__(self, device=0):
+        self.handle = C.c_void_p()
+        check(lib().yalps_ctx_create(device, C.byref(self.handle)))
+
+    def close(self):
+        if self.handle:
+            lib().yalps_ctx_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+
+class DeviceTableau:
+    """A tableau resident in HBM."""
+
+    def __init__(self, ctx, width, height_capacity):
+        self.ctx, self.width, self.capacity = ctx, width, height_capacity
+        self.handle = C.c_void_p()
+        check(lib().yalps_tableau_create(ctx.handle, width, height_capacity, C.byref(self.handle)))
+
+    @property
+    def height(self):
+        return lib().yalps_tableau_height(self.handle)
+
+    def upload(self, matrix, height, pos, var):
+        assert matrix.size >= self.width * height and pos.size >= self.width + height
+        check(lib().yalps_tableau_upload(self.handle, _ptr(matrix, np.float64), height, _ptr(pos, np.int32),
+                                         _ptr(var, np.int32)))
+
+    def download(self, matrix=True, perms=True):
+        h, w = self.height, self.width
+        m = np.empty(h * w, np.float64) if matrix else None
+        pos = np.empty(w + h, np.int32) if perms else None
+        var = np.empty(w + h, np.int32) if perms else None
+        check(lib().yalps_tableau_download(self.handle, _ptr(m, np.float64), _ptr(pos, np.int32), _ptr(var, np.int32)))
+        return m, pos, var
+
+    def download_rhs(self):
+        col0 = np.empty(self.height, np.float64)
+        check(lib().yalps_tableau_download_rhs(self.handle, col0.ctypes.data))
+        return col0
+
+    def copy_from(self, other):
+        check(lib().yalps_tableau_copy(self.handle, other.handle))
+
+    def solve(self, precision=1e-8, max_pivots=8192.0, check_cycles=False):
+        """Returns (status, result, n_pivots, gpu_ms)."""
+        res, npiv, ms = C.c_double(), C.c_int64(), C.c_float()
+        st = check(lib().yalps_tableau_solve(self.handle, precision, float(max_pivots), int(bool(check_cycles)),
+                                             C.byref(res), C.byref(npiv), C.byref(ms)))
+        return STATUS[st], res.value, npiv.value, ms.value
+
+    def pivot(self, row, col):
+        check(lib().yalps_tableau_pivot(self.handle, row, col))
+
+    def bench_sweep(self, row, col, launches):
+        us = C.c_float()
+        check(lib().yalps_tableau_bench_sweep(self.handle, row, col, launches, C.byref(us)))
+        return us.value
+
+    def close(self):
+        if self.handle:
+            lib().yalps_tableau_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+
+def dense_lp(M, N, seed=42.0):
+    """dense-LP(M,N,seed) of SURVEY.md 8(d) as a flat row-major (M+1)x(N+1) tableau."""
+    m = np.zeros((M + 1) * (N + 1), np.float64)
+    lib().yalps_dense_lp_f64(M, N, float(seed), m.ctypes.data)
+    return m
+
+
+def round_to_precision(x, precision):
+    return lib().yalps_round_to_precision(x, precision)
