@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py -- fp64 pivots/sec on a dense tableau (BASELINE.json metric), MI355X.
+
+A "step" = one complete two-phase simplex solve of dense-LP(2048,2048,seed) (BASELINE config 2:
+tableau 2049 x 2049 fp64, 3923 pivots for seed 42) by the HIP path, starting from a pristine
+copy of the tableau that is already resident in HBM.  value = pivots executed / wall time.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--size 2048]
+  N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+         one process per GPU; every rank solves its own LP (seed 42 + rank) -- independent
+         sub-problems shard with no data-path collective (weak scaling); torch.distributed
+         (RCCL) only provides the barriers and the max-over-ranks reduction of the time.
+
+Extra objects on the JSON line (N == 1 / rank 0 only):
+  roofline      the dominant (only) kernel, pivot_kernel: ONE launch = one complete pivot
+                (selection + pivot-row normalise + rank-1 elimination of the whole tableau).
+                achieved = algorithmic bytes per launch (SURVEY.md 8d:
+                16*(h-1)*w + 16*w + 8*(h-1) + 8*(w-1) + 16*(h-1)) / average launch duration, where
+                the duration is HIP-event time over the timed region's pivot loops on the
+                library's own stream divided by the pivots executed (includes launch gaps and the
+                few no-op launches after termination, i.e. it is slightly pessimistic).
+  apply_only    the same kernel in APPLY mode (fixed pivot, no selection) launched back to back,
+                HIP events: isolates the elimination from the selection chain.
+  cpu_baseline  the CPU oracle (scalar C restatement of the reference, 1 thread) timed on the
+                same LP on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes_per_pivot(h, w):
+    # SURVEY.md section 8(d)
+    return 16 * (h - 1) * w + 16 * w + 8 * (h - 1) + 8 * (w - 1) + 16 * (h - 1)
+
+
+def cpu_baseline(M, N, seed, budget_pivots):
+    """Oracle (kind "port") on a bounded sample: the first `budget_pivots` pivots of the same LP
+    (all of them by default: 3923 pivots of the 2049x2049 tableau take ~7-10 s on one core)."""
+    from tests import _oracle
+    orc = _oracle.load()
+    w, h = N + 1, M + 1
+    m = orc.dense_lp(M, N, seed)
+    pos = np.arange(w + h, dtype=np.int32)
+    var = pos.copy()
+    t0 = time.perf_counter()
+    _, _, npiv, _ = orc.simplex(m, w, h, pos, var, max_pivots=budget_pivots)
+    dt = time.perf_counter() - t0
+    return {"value": npiv / dt, "unit": "pivots/s", "cores": 1, "kind": "port",
+            "sample": "%d pivots of dense-LP(%d,%d,seed=%d), oracle/simplex_oracle.c -O2 -ffp-contract=off, %.1f s, host has %d cores"
+                      % (npiv, M, N, seed, dt, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=2048, help="M = N of dense-LP(M,N,seed)")
+    ap.add_argument("--cpu-pivots", type=float, default=float("inf"),
+                    help="oracle sample: first N pivots of the same LP (default: the whole solve, ~7 s; 0 = skip)")
+    ap.add_argument("--sweep-launches", type=int, default=400)
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from yalps_amd import _native
+    M = N = args.size
+    w, h = N + 1, M + 1
+    seed = 42 + rank
+    ctx = _native.Context(local_rank)
+    pristine = _native.DeviceTableau(ctx, w, h)
+    work = _native.DeviceTableau(ctx, w, h)
+    m = _native.dense_lp(M, N, seed)
+    ident = np.arange(w + h, dtype=np.int32)
+    pristine.upload(m, h, ident, ident.copy())  # input resident in HBM before the timed region
+
+    def step():
+        work.copy_from(pristine)
+        return work.solve(max_pivots=float("inf"))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        status, result, npiv, _ = step()
+    barrier()
+    t0 = time.perf_counter()
+    pivots = 0
+    gpu_ms = 0.0
+    for _ in range(args.steps):
+        status, result, npiv, ms = step()
+        pivots += npiv
+        gpu_ms += ms
+    barrier()
+    dt = time.perf_counter() - t0
+    assert status == "optimal", status
+    if seed == 42 and args.size == 2048:  # known answer of the reference
+        assert (npiv, result) == (3923, -1022.09813705), (npiv, result)
+
+    tot = torch.tensor([dt, float(pivots)], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        tmax = tot.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dt_max, pivots_all = tmax[0].item(), tot[1].item()
+    else:
+        dt_max, pivots_all = dt, float(pivots)
+
+    out = None
+    if rank == 0:
+        bpp = algorithmic_bytes_per_pivot(h, w)
+        out = {
+            "metric": "fp64 pivots/sec on dense m x n tableau", "value": pivots_all / dt_max, "unit": "pivots/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt_max / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "dense-LP(%d,%d,seed=42+rank): tableau %dx%d fp64, full two-phase simplex solve "
+                                   "per step (%d pivots on rank 0), one independent LP per GPU" % (M, N, h, w, npiv),
+                       "pivots_per_step": npiv, "objective_cell": result},
+        }
+        if world == 1:
+            us = 1e3 * gpu_ms / pivots
+            ach = bpp / (us * 1e-6) / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                               "frac": ach / HBM_PEAK_GBPS, "traffic": None, "kernel": "pivot_kernel<1024,1,9,9>",
+                               "avg_us": us, "bytes_per_launch": bpp,
+                               "note": "one launch = one pivot; HIP events over the timed pivot loops / pivots"}
+            work.copy_from(pristine)
+            us_apply = work.bench_sweep(h // 2, w // 2, args.sweep_launches)
+            out["apply_only"] = {"avg_us": us_apply, "achieved_GBps": bpp / (us_apply * 1e-6) / 1e9,
+                                 "note": "pivot_kernel in APPLY mode, fixed pivot, back-to-back launches"}
+            if args.cpu_pivots > 0:
+                out["cpu_baseline"] = cpu_baseline(M, N, seed, args.cpu_pivots)
+    work.close()
+    pristine.close()
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

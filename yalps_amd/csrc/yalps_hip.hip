@@ -4,16 +4,25 @@
 // behind the C ABI of include/yalps_hip.h.  Written for gfx950 only.
 //
 // Device-side structure (DESIGN.md has the full picture):
-//   * tableau resident in HBM, row-major, rows padded to a 128-byte pitch;
-//   * per pivot TWO kernels on one stream, captured 64 pairs at a time in a hipGraph:
-//       select_kernel  (1 workgroup, 1024 lanes): loop control, phase-1 / phase-2 scans as
-//                      64-lane wavefront arg-reductions with lowest-index tie-break, cycle
-//                      detector, pivot-row normalise, and the look-ahead pricing of the NEXT
-//                      entering column;
-//       sweep_kernel   (chip-wide): the rank-1 fp64 row elimination (src/simplex.ts:27-38),
-//                      16 B per lane coalesced, pivot-row slice held in registers, which also
-//                      mirrors the next entering column and the RHS column into contiguous
-//                      side arrays so the next ratio test never does a strided read;
+//   * tableau resident in HBM.  Column 0 (the RHS column) lives in its own contiguous array
+//     `rhs[h]`; the variable columns 1..w-1 live row-major in `mat[h][pitch]` (128-byte rows),
+//     so every row is a whole number of 16-byte lane units and the ratio-test inputs are
+//     contiguous.
+//   * ONE kernel launch per pivot (pivot_kernel, mode FUSED), 64 launches per hipGraph replay:
+//       - every workgroup spans the full row width (lane = 16-byte unit(s) of a row) and owns
+//         the rows b, b+NB, b+2NB, ...;
+//       - prologue, redundantly in every workgroup: reduce the per-workgroup partials the
+//         previous launch left (min-ratio candidates / most-negative-RHS candidates) with
+//         64-lane arg-min reductions (lowest index wins ties) -> leaving row; fetch that row,
+//         normalise it in registers (src/simplex.ts:14-25) and price the objective row as it
+//         will be after this pivot -> next entering column (look-ahead);
+//       - body: rank-1 fp64 elimination of the workgroup's rows (src/simplex.ts:27-38), all row
+//         loads of a batch in flight at once; the updated entries of the next entering column
+//         and of the RHS are picked out of the registers they already sit in and reduced to
+//         this workgroup's partial for the next launch.
+//     The only grid-wide dependency (arg-min over all rows) is carried by the kernel boundary.
+//   * checkCycles=true runs the same kernel as alternating DECIDE (one workgroup: selection +
+//     the reference's cycle detector) and APPLY launches.
 //   * no host round trip per pivot: termination is decided on the device, later launches of a
 //     batch turn into no-ops, the host polls the state once per batch.
 //
@@ -40,47 +49,66 @@
 namespace {
 
 constexpr int RUNNING = -1;
-constexpr int SELECT_THREADS = 1024;
-constexpr int SWEEP_THREADS = 256;
-constexpr int SWEEP_ROWS = 8;  // rows in flight per lane (16 B each)
-constexpr int PAIRS_PER_GRAPH = 64;
-// A quiet NaN with a payload no arithmetic produces: marks pivot-row entries that pivot()
-// flushed to zero (src/simplex.ts:18-23), i.e. columns NOT in `nonZeroColumns`.
-constexpr unsigned long long FLUSHED = 0x7FF8C0DEC0DE5EEDull;
+constexpr int MODE_FUSED = 0, MODE_DECIDE = 1, MODE_APPLY = 2;
+constexpr int LAUNCHES_PER_GRAPH = 64; // even: state parity returns to 0 after a replay
+constexpr int MAX_BLOCKS = 1024;       // partial arrays / reduction width
 
-struct alignas(16) YState {
-    int32_t status;  // RUNNING or a YALPS_* status code
-    int32_t phase;   // 1 | 2
-    int32_t pending; // a pivot (row, col) is prepared and the sweep has to apply it
-    int32_t row, col;
-    int32_t la;       // look-ahead: entering column of the NEXT phase-2 iteration (0 = none)
-    int32_t la_valid; // la / cbuf[cur ^ 1] were produced for the tableau as it is now
-    int32_t cur;      // cbuf[cur] holds column `col` as it was before the pending pivot
-    int32_t rhs_valid;
-    int32_t pause; // cycle history full: host must grow it
+// Per-solve constants (host-written once per solve; the cycle-history pointers again on growth).
+struct alignas(16) YConst {
     int32_t height;
     int32_t check_cycles;
-    int64_t hist_len, hist_cap;
+    int64_t hist_cap;
     int32_t *hist_leaving, *hist_entering;
-    double quotient;
+    double precision, max_pivots;
+};
+
+// Dynamic solver state, ping-ponged between launches.  The hot path writes every field from
+// registers (no read-modify-write chain at the end of a launch).
+struct alignas(16) YState {
+    int32_t status;    // RUNNING or a YALPS_* status code
+    int32_t phase;     // 1 | 2
+    int32_t bootstrap; // no partials exist yet: next APPLY/FUSED launch only scans
+    int32_t la;        // column whose min-ratio partials are in part_ratio[pbuf] (0 = none priced)
+    int32_t pbuf;      // which partial buffers the next launch reads
+    int32_t mbuf;      // which tableau buffer holds the current tableau (the other one is written)
+    int32_t pause;     // cycle history full: host must grow it
+    int32_t dec_valid; // DECIDE -> APPLY hand-off
+    int32_t dec_row, dec_col;
+    // basis bookkeeping (src/simplex.ts:7-12) of the pivot just applied, carried out by the NEXT
+    // launch (its loads are then the oldest of that launch instead of the last of this one)
+    int32_t swap_valid, swap_row, swap_col;
+    int32_t pad_;
+    int64_t hist_len;
     double iter; // pivots done in the current phase (src/simplex.ts:69,109)
     double result;
-    double precision, max_pivots;
     int64_t pivots; // total over both phases
 };
 
+struct alignas(16) Part {
+    double key;
+    int32_t idx;
+    int32_t pad_;
+};
+
 struct Desc {
-    double *mat;     // [hcap][pitch]
-    double *cbuf[2]; // [hcap] column staging (current / next entering column)
-    double *rhs;     // [hcap] mirror of column 0
-    double *prow;    // [pitch] normalised pivot row, FLUSHED where pivot() wrote 0.0
+    // The tableau is ping-ponged: a pivot reads buffer [mbuf] and writes buffer [mbuf ^ 1], so no
+    // workgroup ever reads a row (pivot row, objective row, pivot column) that another workgroup
+    // of the same launch is overwriting.
+    double *mat[2]; // [hcap][pitch]: columns 1..w-1 of the reference tableau
+    double *rhs[2]; // [hcap]: column 0
     int32_t *pos, *var;
-    YState *st;
-    int32_t w, pitch, hcap;
+    YState *st;          // [2], ping-pong by launch parity
+    YConst *cst;
+    Part *part_ratio[2]; // [MAX_BLOCKS] each
+    Part *part_rhs[2];
+    int32_t w, n, pitch, hcap; // n = w - 1 variable columns
+    int32_t nb;                // workgroups of an APPLY/FUSED launch = row stride = number of partials
 };
 
 // ------------------------------------------------------------------------------------------
-// 64-lane arg-min with lowest-index tie-break (all four scans of the reference reduce to it)
+// 64-lane arg-min with lowest-index tie-break (all four scans of the reference reduce to it).
+// Built on DPP lane permutes (VALU speed); __shfl_* would go through ds_bpermute, ~1 us per
+// 64-lane (double,int) reduction, which was most of a pivot's fixed cost.
 // ------------------------------------------------------------------------------------------
 struct KI {
     double k;
@@ -91,36 +119,70 @@ __device__ __forceinline__ bool ki_better(double ka, int ia, double kb, int ib) 
     return ka < kb || (ka == kb && ia < ib);
 }
 
-__device__ __forceinline__ KI wave_argmin(KI v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const double ok = __shfl_down(v.k, off, 64);
-        const int oi = __shfl_down(v.i, off, 64);
-        if (ki_better(ok, oi, v.k, v.i)) {
-            v.k = ok;
-            v.i = oi;
-        }
-    }
+// DPP controls: quad_perm [1,0,3,2] / [2,3,0,1], row_half_mirror, row_mirror
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = dpp_i32<CTRL>(__double2loint(v)), hi = dpp_i32<CTRL>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+// every lane of a 16-lane row gets the row's minimum (keys are never NaN)
+__device__ __forceinline__ double row16_min(double v) {
+    v = fmin(v, dpp_f64<DPP_XOR1>(v));
+    v = fmin(v, dpp_f64<DPP_XOR2>(v));
+    v = fmin(v, dpp_f64<DPP_HALF_MIRROR>(v));
+    v = fmin(v, dpp_f64<DPP_MIRROR>(v));
     return v;
 }
+__device__ __forceinline__ int row16_min(int v) {
+    v = min(v, dpp_i32<DPP_XOR1>(v));
+    v = min(v, dpp_i32<DPP_XOR2>(v));
+    v = min(v, dpp_i32<DPP_HALF_MIRROR>(v));
+    v = min(v, dpp_i32<DPP_MIRROR>(v));
+    return v;
+}
+__device__ __forceinline__ double lane_f64(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                            __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ KI row16_argmin(KI v) {
+    KI r;
+    r.k = row16_min(v.k);
+    r.i = row16_min(v.k == r.k ? v.i : INT_MAX);
+    return r;
+}
+// result uniform over the wave
+__device__ __forceinline__ KI wave_argmin(KI v) {
+    const double m = row16_min(v.k);
+    KI r;
+    r.k = fmin(fmin(lane_f64(m, 0), lane_f64(m, 16)), fmin(lane_f64(m, 32), lane_f64(m, 48)));
+    const int i = row16_min(v.k == r.k ? v.i : INT_MAX);
+    r.i = min(min(__builtin_amdgcn_readlane(i, 0), __builtin_amdgcn_readlane(i, 16)),
+              min(__builtin_amdgcn_readlane(i, 32), __builtin_amdgcn_readlane(i, 48)));
+    return r;
+}
 
-// Result broadcast to every lane of the workgroup.  sk / si: 16-entry LDS scratch.
-__device__ __forceinline__ KI block_argmin(KI v, double *sk, int *si) {
+// Result broadcast to every lane of the workgroup.  sk / si: [2][16] LDS scratch, `slot`
+// alternates between consecutive calls (so one barrier per call is enough).
+template <int T>
+__device__ __forceinline__ KI block_argmin(KI v, double (*sk)[16], int (*si)[16], int slot) {
+    constexpr int NW = T / 64;
     v = wave_argmin(v);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (lane == 0) {
-        sk[wv] = v.k;
-        si[wv] = v.i;
+        sk[slot][wv] = v.k;
+        si[slot][wv] = v.i;
     }
     __syncthreads();
     KI r;
-    r.k = lane < nw ? sk[lane] : INFINITY;
-    r.i = lane < nw ? si[lane] : INT_MAX;
-    r = wave_argmin(r);
-    r.k = __shfl(r.k, 0, 64);
-    r.i = __shfl(r.i, 0, 64);
-    return r;
+    r.k = (lane & 15) < NW ? sk[slot][lane & 15] : INFINITY;
+    r.i = (lane & 15) < NW ? si[slot][lane & 15] : INT_MAX;
+    return row16_argmin(r); // every 16-lane row holds all NW wave results
 }
 
 // JS Math.round (halves toward +inf) and roundToPrecision (src/util.ts:1-4)
@@ -134,25 +196,10 @@ __host__ __device__ inline double round_to_precision(double num, double precisio
     return js_round((num + 2.220446049250313e-16) * rounding) / rounding;
 }
 
-// Strided read of one tableau column into a contiguous array (only on the slow paths: first
-// iteration, phase 1, or when no look-ahead column was available).
-__device__ __forceinline__ void gather_column(const Desc &d, int h, int col, double *dst) {
-    for (int r = threadIdx.x; r < h; r += blockDim.x) dst[r] = d.mat[(size_t)r * d.pitch + col];
-    __syncthreads();
-}
-
-__device__ __forceinline__ void finish(YState *st, int status, double result) {
-    if (threadIdx.x == 0) {
-        st->status = status;
-        st->result = result;
-        st->pending = 0;
-    }
-}
-
-// src/simplex.ts:44-63 -- every lane tests a set of candidate cycle lengths.
-__device__ __forceinline__ bool has_cycle(YState *st, int leaving, int entering, int *flag) {
-    int32_t *hl = st->hist_leaving, *he = st->hist_entering;
-    const int64_t len = st->hist_len + 1;
+// src/simplex.ts:44-63 -- every lane tests a set of candidate cycle lengths (DECIDE launches).
+__device__ __forceinline__ bool has_cycle(const YConst *C, int64_t hist_len, int leaving, int entering, int *flag) {
+    int32_t *hl = C->hist_leaving, *he = C->hist_entering;
+    const int64_t len = hist_len + 1;
     if (threadIdx.x == 0) {
         hl[len - 1] = leaving;
         he[len - 1] = entering;
@@ -176,313 +223,531 @@ __device__ __forceinline__ bool has_cycle(YState *st, int leaving, int entering,
     return *flag != 0;
 }
 
-// Pivot bookkeeping + pivot-row normalise (src/simplex.ts:6-25) for the pivot (row, col);
-// cb = column `col` before the pivot.  With lookahead (phase 2) it also prices the objective
-// row as it will be AFTER this pivot and returns the next entering column (0 = none).
-__device__ __forceinline__ int prepare_pivot(const Desc &d, YState *st, int row, int col, const double *cb,
-                                             bool lookahead, double precision, double *sk, int *si) {
-    const int w = d.w;
-    const double q = cb[row];
-    double *mrow = d.mat + (size_t)row * d.pitch;
-    const double *m0 = d.mat;
-    const double coef0 = cb[0];
-    const bool touched0 = fabs(coef0) > 1e-16;
-    const double inv_q = 1.0 / q;
-    const double neg0 = -coef0 / q;
-    KI best = {INFINITY, INT_MAX};
-    for (int c = threadIdx.x; c < w; c += blockDim.x) {
-        const double v = mrow[c];
-        const bool nz = fabs(v) > 1e-16;
-        const double pn = nz ? v / q : 0.0;
-        mrow[c] = (c == col) ? inv_q : pn;
-        d.prow[c] = nz ? pn : __longlong_as_double((long long)FLUSHED);
-        if (lookahead && c >= 1) {
-            double o = m0[c];
-            if (touched0) {
-                if (c == col)
-                    o = neg0;
-                else if (nz) {
-                    const double prod = coef0 * pn;
-                    o = o - prod;
-                }
+// Sout = Sin, 16 bytes at a time, straight from global to global (a `YState s = *Sin` local copy
+// is turned into a per-lane LDS array by hipcc).
+__device__ __forceinline__ void state_copy(YState *dst, const YState *src) {
+    static_assert(sizeof(YState) % 16 == 0, "YState is copied as int4 words");
+    const int4 *s4 = reinterpret_cast<const int4 *>(src);
+    int4 *d4 = reinterpret_cast<int4 *>(dst);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(YState) / 16; i++) d4[i] = s4[i];
+}
+
+// 16-byte row load; nt = non-temporal (streaming) cache policy
+__device__ __forceinline__ double2 ld_row(const double *p, bool nt) {
+    if (nt) return make_double2(__builtin_nontemporal_load(p), __builtin_nontemporal_load(p + 1));
+    return *reinterpret_cast<const double2 *>(p);
+}
+
+// By-value selects: a reference + runtime element index would turn into a dynamically indexed
+// private array, which hipcc places in scratch / LDS instead of registers.
+__device__ __forceinline__ double elem(double2 v, int e) {
+    const double a = v.x, b = v.y;
+    return e ? b : a;
+}
+__device__ __forceinline__ double2 with_elem(double2 v, int e, double x) {
+    return make_double2(e ? v.x : x, e ? x : v.y);
+}
+
+// ------------------------------------------------------------------------------------------
+// pivot_kernel<T lanes, J units per lane per row, R rows per lane and batch, D rows prefetched>
+//   lane `tid`, unit j  <->  mat columns 2*(tid + j*T) + {0,1}  <->  reference columns +1
+//   workgroup b owns rows b, b+NB, b+2NB, ...; lanes 0..R-1 of wave 0 also own the scalar side
+//   (RHS entry, pivot-column entry, ratio) of row g = lane.
+// Load discipline: every load is unconditional with an in-bounds (possibly dummy) address and
+// the body is fully unrolled, so hipcc can count the load queue (s_waitcnt vmcnt(N)) instead of
+// draining it; vmcnt retires in issue order, hence the issue order below is deliberate.
+// ------------------------------------------------------------------------------------------
+template <int T, int J, int R, int D>
+__global__ __launch_bounds__(T) void pivot_kernel(Desc d, int parity, int mode, int force) {
+    __shared__ double sk[2][16];
+    __shared__ int si[2][16];
+    __shared__ double sh_la[2][R]; // next entering column's entries of my rows (ping-pong per batch)
+    __shared__ int cyc_flag;
+
+    const int tid = threadIdx.x, NB = d.nb, b = blockIdx.x;
+    const YState *Sin = d.st + parity;
+    YState *Sout = d.st + (parity ^ 1);
+    const YConst *C = d.cst;
+    if (Sin->status != RUNNING || Sin->pause) {
+        if (b == 0 && tid == 0) state_copy(Sout, Sin);
+        return;
+    }
+    const int h = C->height, n = d.n, pitch = d.pitch;
+    const double precision = C->precision, max_pivots = C->max_pivots;
+    const int64_t pivots_in = Sin->pivots, hist_len_in = Sin->hist_len;
+    // (0) pending basis bookkeeping of the previous pivot: its two loads are the oldest of this
+    // launch, its four stores are fire-and-forget at the end (or before any early return)
+    const bool swapper = b == 0 && tid == 0 && Sin->swap_valid;
+    const int sw_row = Sin->swap_row, sw_col = Sin->swap_col;
+    int sw_leaving = 0, sw_entering = 0;
+    bool swapped = false;
+    if (swapper) {
+        sw_leaving = d.var[d.w + sw_row];
+        sw_entering = d.var[sw_col];
+    }
+    auto apply_swap = [&]() {
+        if (swapper && !swapped) {
+            d.var[d.w + sw_row] = sw_entering;
+            d.var[sw_col] = sw_leaving;
+            d.pos[sw_leaving] = sw_col;
+            d.pos[sw_entering] = d.w + sw_row;
+        }
+        swapped = true;
+    };
+    // every field of the next state, from registers
+    auto write_state = [&](int status, int phase_, int bootstrap_, int la_, int pbuf_, int mbuf_, int pause_,
+                           int dec_valid_, int dec_row_, int dec_col_, int swap_valid_, int swap_row_,
+                           int swap_col_, int64_t hist_len_, double iter_, double result_, int64_t pivots_) {
+        Sout->status = status;
+        Sout->phase = phase_;
+        Sout->bootstrap = bootstrap_;
+        Sout->la = la_;
+        Sout->pbuf = pbuf_;
+        Sout->mbuf = mbuf_;
+        Sout->pause = pause_;
+        Sout->dec_valid = dec_valid_;
+        Sout->dec_row = dec_row_;
+        Sout->dec_col = dec_col_;
+        Sout->swap_valid = swap_valid_;
+        Sout->swap_row = swap_row_;
+        Sout->swap_col = swap_col_;
+        Sout->pad_ = 0;
+        Sout->hist_len = hist_len_;
+        Sout->iter = iter_;
+        Sout->result = result_;
+        Sout->pivots = pivots_;
+    };
+    // Every launch that gets past the selection flips both ping-pong indices, so in FUSED graphs
+    // they equal the launch parity (a kernel argument): the first loads need not wait for the state.
+    const int pbuf = mode == MODE_FUSED ? parity : Sin->pbuf;
+    const int mbuf = mode == MODE_FUSED ? parity : Sin->mbuf;
+    const int la_in = Sin->la;
+    const double *__restrict__ matA = d.mat[mbuf];
+    const double *__restrict__ rhsA = d.rhs[mbuf];
+    double *__restrict__ matB = d.mat[mbuf ^ 1];
+    double *__restrict__ rhsB = d.rhs[mbuf ^ 1];
+    const bool bootstrap = Sin->bootstrap != 0;
+    const int phase_in = Sin->phase;
+    const double iter_in = Sin->iter;
+    int phase = phase_in;
+    double iter = iter_in;
+    bool phase_switched = false;
+    int slot = 0; // block_argmin scratch ping-pong
+
+    // lane's column offsets (lanes past the row end use column 0: in-bounds dummy)
+    int cofs[J];
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+        const int c0 = 2 * (tid + j * T);
+        cofs[j] = c0 < pitch ? c0 : 0;
+    }
+
+    // (1) control loads first (oldest in the queue): partials of the previous launch, objective row
+    Part p_rhs, p_ratio;
+    {
+        const int pi = tid < NB ? tid : 0;
+        p_rhs = d.part_rhs[pbuf][pi];
+        p_ratio = d.part_ratio[pbuf][pi];
+    }
+    double2 o[J]; // objective row slice (reduced costs)
+#pragma unroll
+    for (int j = 0; j < J; j++) o[j] = *reinterpret_cast<const double2 *>(matA + cofs[j]);
+
+    // (2) the first D rows of my first batch: they depend on nothing the selection decides, so
+    // they stream in while the selection runs
+    double2 x[R][J];
+    {
+#pragma unroll
+        for (int g = 0; g < D; g++) {
+            const int r = b + NB * g;
+            const double *mr = matA + (size_t)(r < h ? r : b) * pitch;
+#pragma unroll
+            for (int j = 0; j < J; j++) x[g][j] = ld_row(mr + cofs[j], false);
+        }
+    }
+
+    int row = 0, col = 0;
+    bool have_pivot = false, pv_loaded = false;
+    double2 pv[J]; // pivot row slice: raw, then normalised
+#pragma unroll
+    for (int j = 0; j < J; j++) pv[j] = make_double2(0.0, 0.0);
+
+    // ---------------- decide: which pivot, or stop (src/simplex.ts:66-142 minus pivot()) ------
+    if (mode != MODE_APPLY && !bootstrap) {
+        int term = RUNNING;
+        double term_result = NAN;
+        for (;;) {
+            if (!(iter < max_pivots)) { // loop bounds :69,109 -> "cycled" :102,141
+                term = YALPS_CYCLED;
+                break;
             }
-            if (o > precision && ki_better(-o, c, best.k, best.i)) {
-                best.k = -o;
-                best.i = c;
+            if (phase == 1) {
+                // leaving row: most negative RHS, strict <, first wins (:111-119)
+                KI c = {INFINITY, INT_MAX};
+                if (tid < NB) {
+                    c.k = p_rhs.key;
+                    c.i = p_rhs.idx;
+                }
+                c = block_argmin<T>(c, sk, si, slot);
+                slot ^= 1;
+                if (c.i == INT_MAX) { // :120 tail call of phase2: fresh counter and history
+                    phase = 2;
+                    iter = 0.0;
+                    phase_switched = true;
+                    continue;
+                }
+                row = c.i;
+                // entering column: max -M[0,c]/M[row,c] over M[row,c] < -precision (:123-134)
+                const double *mrow = matA + (size_t)row * pitch;
+                KI e = {INFINITY, INT_MAX};
+#pragma unroll
+                for (int j = 0; j < J; j++) {
+                    const int c0 = 2 * (tid + j * T);
+                    pv[j] = *reinterpret_cast<const double2 *>(mrow + cofs[j]);
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        const double coefficient = elem(pv[j], k);
+                        if (c0 + k < n && coefficient < -precision) {
+                            const double ratio = -elem(o[j], k) / coefficient;
+                            if (ratio > -INFINITY && ki_better(-ratio, c0 + k + 1, e.k, e.i)) {
+                                e.k = -ratio;
+                                e.i = c0 + k + 1;
+                            }
+                        }
+                    }
+                }
+                pv_loaded = true;
+                e = block_argmin<T>(e, sk, si, slot);
+                slot ^= 1;
+                if (e.i == INT_MAX) { // :135
+                    term = YALPS_INFEASIBLE;
+                    break;
+                }
+                col = e.i;
+                break;
+            } else {
+                col = la_in; // Dantzig pricing (:71-79) was done by the previous launch
+                if (col == 0) { // :80
+                    term = YALPS_OPTIMAL;
+                    term_result = round_to_precision(rhsA[0], precision);
+                    break;
+                }
+                // leaving row: min-ratio test with the early break (:83-95); the partials carry
+                // key = -inf for "ratio <= precision" rows so the lowest such index wins
+                KI c = {INFINITY, INT_MAX};
+                if (tid < NB) {
+                    c.k = p_ratio.key;
+                    c.i = p_ratio.idx;
+                }
+                c = block_argmin<T>(c, sk, si, slot);
+                slot ^= 1;
+                if (c.i == INT_MAX) { // :96
+                    term = YALPS_UNBOUNDED;
+                    term_result = (double)col;
+                    break;
+                }
+                row = c.i;
+                break;
+            }
+        }
+        int64_t hist_len = phase_switched ? 0 : hist_len_in;
+        if (term != RUNNING) {
+            apply_swap();
+            if (b == 0 && tid == 0)
+                write_state(term, phase, 0, la_in, pbuf, mbuf, 0, 0, 0, 0, 0, 0, 0, hist_len, iter, term_result,
+                            pivots_in);
+            return;
+        }
+        if (C->check_cycles) { // :98,137 (DECIDE launches only: one workgroup)
+            if (hist_len >= C->hist_cap) { // history full: the host grows it; nothing is consumed
+                apply_swap();
+                if (tid == 0)
+                    write_state(RUNNING, phase, 0, la_in, pbuf, mbuf, 1, 0, 0, 0, 0, 0, 0, hist_len, iter, NAN,
+                                pivots_in);
+                return;
+            }
+            apply_swap(); // the detector reads the basis as it is now
+            __syncthreads();
+            const bool cyc = has_cycle(C, hist_len, d.var[d.w + row], d.var[col], &cyc_flag);
+            hist_len += 1;
+            if (cyc) {
+                if (tid == 0)
+                    write_state(YALPS_CYCLED, phase, 0, la_in, pbuf, mbuf, 0, 0, 0, 0, 0, 0, 0, hist_len, iter, NAN,
+                                pivots_in);
+                return;
+            }
+        }
+        have_pivot = true;
+        if (mode == MODE_DECIDE) {
+            apply_swap();
+            if (b == 0 && tid == 0)
+                write_state(RUNNING, phase, 0, la_in, pbuf, mbuf, 0, 1, row, col, 0, 0, 0, hist_len, iter + 1.0, NAN,
+                            pivots_in + 1);
+            return;
+        }
+    } else if (mode == MODE_APPLY && Sin->dec_valid) {
+        row = Sin->dec_row;
+        col = Sin->dec_col;
+        have_pivot = true;
+    }
+    if (!have_pivot && !bootstrap) { // APPLY with nothing decided
+        apply_swap();
+        if (b == 0 && tid == 0 && !(force & 1))
+            write_state(RUNNING, phase_in, 0, la_in, pbuf, mbuf, 0, 0, 0, 0, 0, 0, 0, hist_len_in, iter_in, NAN,
+                        pivots_in);
+        return;
+    }
+
+    // ---------------- prepare: pivot row normalise + look-ahead pricing -----------------------
+    // owner lane/unit/element of a reference column c (c >= 1): mat column c-1
+    const int ucol = (col - 1) >> 1, ecol = (col - 1) & 1;
+    const int col_tid = have_pivot ? ucol % T : -1, col_j = have_pivot ? ucol / T : -1;
+    const int colx = have_pivot ? col - 1 : 0; // in-bounds even without a pivot
+    // (3) pivot row, quotient, objective row's pivot-column entry
+    if (!pv_loaded) {
+        const double *mrow = matA + (size_t)row * pitch;
+#pragma unroll
+        for (int j = 0; j < J; j++) pv[j] = *reinterpret_cast<const double2 *>(mrow + cofs[j]);
+    }
+    const double q_ld = matA[(size_t)row * pitch + colx], coef0_ld = matA[colx];
+    const double rhs_row = rhsA[row];
+    const double q = have_pivot ? q_ld : 1.0, coef0 = have_pivot ? coef0_ld : 0.0;
+
+    unsigned nzmask = 0; // bit (2j+k): pivot-row entry is in nonZeroColumns (:18-23)
+    if (have_pivot) {    // src/simplex.ts:14-25
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const double v = elem(pv[j], k);
+                const bool nz = fabs(v) > 1e-16;
+                pv[j] = with_elem(pv[j], k, nz ? v / q : 0.0);
+                if (nz) nzmask |= 1u << (2 * j + k);
             }
         }
     }
-    if (threadIdx.x == 0) {
-        // basis bookkeeping, src/simplex.ts:7-12
+    const double inv_q = 1.0 / q; // :25 (the pivot entry becomes 1/quotient)
+    int la = 0, la_tid = -1, la_j = -1, ela = 0;
+    bool la_known = false;
+
+    // ---------------- body: eliminate my rows into the other buffer, emit partials ------------
+    KI cand_ratio = {INFINITY, INT_MAX}, cand_rhs = {INFINITY, INT_MAX}; // lanes 0..R-1
+    for (int i0 = 0; b + NB * i0 < h; i0 += R) {
+        const int r_first = b + NB * i0;
+        // (4) pivot-column entries of my rows (uniform per row) and, lane g, the RHS of row g
+        double coef[R];
+#pragma unroll
+        for (int g = 0; g < R; g++) {
+            const int r = b + NB * (i0 + g);
+            coef[g] = matA[(size_t)(r < h ? r : r_first) * pitch + colx];
+        }
+        const int my_r = b + NB * (i0 + tid);
+        const bool my_live = tid < R && my_r < h;
+        const double rr = rhsA[my_live ? my_r : 0];
+        if (i0 > 0) { // later batches: prefetch their first D rows (batch 0's came in at the top)
+#pragma unroll
+            for (int g = 0; g < D; g++) {
+                const int r = b + NB * (i0 + g);
+                const double *mr = matA + (size_t)(r < h ? r : r_first) * pitch;
+#pragma unroll
+                for (int j = 0; j < J; j++) x[g][j] = ld_row(mr + cofs[j], false);
+            }
+        }
+        // lane g: scalar side of row g -- RHS entry (:33 at c = 0) and pivot-column entry (:36)
+        double my_rhs = rr, my_val = 0.0;
+        bool my_val_set = false;
+        if (my_live && have_pivot) {
+            double my_coef = 0.0;
+#pragma unroll
+            for (int g = 0; g < R; g++)
+                if (tid == g) my_coef = coef[g];
+            const bool nz_rhs = fabs(rhs_row) > 1e-16;
+            const double pn_rhs = nz_rhs ? rhs_row / q : 0.0;
+            if (my_r == row) {
+                my_rhs = pn_rhs;
+            } else if (fabs(my_coef) > 1e-16) {
+                if (nz_rhs) {
+                    const double prod = my_coef * pn_rhs;
+                    my_rhs = rr - prod;
+                }
+                const double nq = -my_coef / q;
+                matB[(size_t)my_r * pitch + colx] = nq; // the owner lane stores only the other half
+                my_val = nq; // what this row holds in column `col` from now on
+                my_val_set = true;
+            }
+            rhsB[my_r] = my_rhs;
+        } else if (my_live) {
+            rhsB[my_r] = rr; // bootstrap: carry over
+        }
+        // rows: eliminate + write to the other buffer, row by row, with the loads of the next
+        // rows in flight.  Rows the reference leaves untouched (:31) are carried over unchanged.
+#pragma unroll
+        for (int g = 0; g < R; g++) {
+            const int r = b + NB * (i0 + g);
+            const bool live = r < h;
+            const double c = coef[g];
+            const bool act = have_pivot && live && r != row && fabs(c) > 1e-16;
+            if (have_pivot && live && r == row) {
+#pragma unroll
+                for (int j = 0; j < J; j++) {
+                    x[g][j] = pv[j];
+                    if (tid == col_tid && j == col_j) x[g][j] = with_elem(x[g][j], ecol, inv_q);
+                }
+            } else if (act) {
+#pragma unroll
+                for (int j = 0; j < J; j++) {
+                    if (nzmask & (1u << (2 * j))) {
+                        const double prod = c * pv[j].x;
+                        x[g][j].x = x[g][j].x - prod;
+                    }
+                    if (nzmask & (1u << (2 * j + 1))) {
+                        const double prod = c * pv[j].y;
+                        x[g][j].y = x[g][j].y - prod;
+                    }
+                }
+            }
+            if (live) { // (a bootstrap launch just carries the tableau over)
+                double *mr = matB + (size_t)r * pitch;
+#pragma unroll
+                for (int j = 0; j < J; j++) {
+                    const int c0 = 2 * (tid + j * T);
+                    if (c0 >= pitch) continue;
+                    if (act && tid == col_tid && j == col_j) // lane g of wave 0 stores -coef/quotient
+                        mr[c0 + (ecol ^ 1)] = elem(x[g][j], ecol ^ 1);
+                    else if (force & 64) { // streaming (non-temporal) stores; YALPS_HIP_NT=0 turns them off
+                        __builtin_nontemporal_store(x[g][j].x, mr + c0);
+                        __builtin_nontemporal_store(x[g][j].y, mr + c0 + 1);
+                    } else
+                        *reinterpret_cast<double2 *>(mr + c0) = x[g][j];
+                }
+            }
+            if (g + D < R) { // keep D rows in flight
+                const int rn = b + NB * (i0 + g + D);
+                const double *mr = matA + (size_t)(rn < h ? rn : r_first) * pitch;
+#pragma unroll
+                for (int j = 0; j < J; j++) x[g + D][j] = ld_row(mr + cofs[j], false);
+            }
+        }
+        // Dantzig pricing (:71-79) of the objective row as it is AFTER this pivot (as it is, when
+        // bootstrapping) -> entering column `la` of the next iteration
+        if (!la_known) {
+            la_known = true;
+            const bool touched0 = have_pivot && fabs(coef0) > 1e-16;
+            KI best = {INFINITY, INT_MAX};
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                const int c0 = 2 * (tid + j * T);
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    double ov = elem(o[j], k);
+                    if (touched0) {
+                        if (tid == col_tid && j == col_j && k == ecol)
+                            ov = -coef0 / q;
+                        else if (nzmask & (1u << (2 * j + k))) {
+                            const double prod = coef0 * elem(pv[j], k);
+                            ov = ov - prod;
+                        }
+                    }
+                    if (c0 + k < n && ov > precision && ki_better(-ov, c0 + k + 1, best.k, best.i)) {
+                        best.k = -ov;
+                        best.i = c0 + k + 1;
+                    }
+                }
+            }
+            best = block_argmin<T>(best, sk, si, slot);
+            slot ^= 1;
+            la = best.i == INT_MAX ? 0 : best.i;
+            const int ula = (la - 1) >> 1;
+            ela = (la - 1) & 1;
+            la_tid = la > 0 ? ula % T : -1;
+            la_j = la > 0 ? ula / T : -1;
+        }
+        // entries of my rows in column `la` (x holds the rows as written), for lanes 0..R-1
+        if (tid == la_tid) {
+#pragma unroll
+            for (int g = 0; g < R; g++)
+#pragma unroll
+                for (int j = 0; j < J; j++)
+                    if (j == la_j) sh_la[(i0 / R) & 1][g] = elem(x[g][j], ela);
+        }
+        __syncthreads(); // sh_la of this batch visible to lanes 0..R-1
+        // candidates of my row for the next launch's scans
+        if (my_live && my_r >= 1) {
+            if (my_rhs < -precision && ki_better(my_rhs, my_r, cand_rhs.k, cand_rhs.i)) {
+                cand_rhs.k = my_rhs;
+                cand_rhs.i = my_r;
+            }
+            if (la > 0) {
+                const double value = (my_val_set && la == col) ? my_val : sh_la[(i0 / R) & 1][tid];
+                if (value > precision) {
+                    const double ratio = my_rhs / value;
+                    if (ratio < INFINITY) {
+                        const double key = (ratio <= precision) ? -INFINITY : ratio;
+                        if (ki_better(key, my_r, cand_ratio.k, cand_ratio.i)) {
+                            cand_ratio.k = key;
+                            cand_ratio.i = my_r;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (tid < 64) { // R <= 16 < 64: wave 0 holds every candidate
+        cand_ratio = wave_argmin(cand_ratio);
+        cand_rhs = wave_argmin(cand_rhs);
+        if (tid == 0) {
+            Part p;
+            p.pad_ = 0;
+            p.key = cand_ratio.k;
+            p.idx = cand_ratio.i;
+            d.part_ratio[pbuf ^ 1][b] = p;
+            p.key = cand_rhs.k;
+            p.idx = cand_rhs.i;
+            d.part_rhs[pbuf ^ 1][b] = p;
+        }
+    }
+    apply_swap();
+    if (b == 0 && tid == 0 && !(force & 1)) {
+        const bool counted = have_pivot && mode == MODE_FUSED; // DECIDE already counted an APPLY's pivot
+        write_state(RUNNING, phase, 0, la, pbuf ^ 1, mbuf ^ 1, 0, 0, 0, 0, have_pivot ? 1 : 0, row, col,
+                    (mode == MODE_FUSED && phase_switched) ? 0 : hist_len_in, counted ? iter + 1.0 : iter, NAN,
+                    counted ? pivots_in + 1 : pivots_in);
+    }
+}
+
+// Applies a pending basis swap left by the last APPLY launch (single-pivot API).
+__global__ void flush_swap_kernel(Desc d, int parity) {
+    YState *S = d.st + parity;
+    if (threadIdx.x == 0 && blockIdx.x == 0 && S->swap_valid) {
+        const int w = d.w, row = S->swap_row, col = S->swap_col;
         const int leaving = d.var[w + row], entering = d.var[col];
         d.var[w + row] = entering;
         d.var[col] = leaving;
         d.pos[leaving] = col;
         d.pos[entering] = w + row;
-    }
-    int la = 0;
-    if (lookahead) {
-        const KI r = block_argmin(best, sk, si);
-        la = r.i == INT_MAX ? 0 : r.i;
-    } else {
-        __syncthreads();
-    }
-    // the pivot row is skipped by the sweep: mirror its new entries here
-    if (threadIdx.x == 0) {
-        d.rhs[row] = mrow[0];
-        if (la > 0) d.cbuf[st->cur ^ 1][row] = mrow[la];
-        st->quotient = q;
-    }
-    return la;
-}
-
-// ------------------------------------------------------------------------------------------
-// select_kernel: one workgroup; everything of phase1()/phase2() except the elimination
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(SELECT_THREADS) void select_kernel(Desc d) {
-    __shared__ double sk[16];
-    __shared__ int si[16];
-    __shared__ int cyc_flag;
-    YState *st = d.st;
-    if (st->status != RUNNING || st->pause) return;
-    const int h = st->height, w = d.w;
-    const double precision = st->precision, max_pivots = st->max_pivots;
-    int phase = st->phase, cur = st->cur;
-    double iter = st->iter;
-    bool la_valid = st->la_valid != 0;
-    const int la = st->la;
-    const int tid = threadIdx.x, nt = blockDim.x;
-
-    if (!st->rhs_valid) gather_column(d, h, 0, d.rhs);
-
-    int row = 0, col = 0;
-    for (;;) {
-        if (!(iter < max_pivots)) { // src/simplex.ts:69,109 loop bound; :102,141
-            finish(st, YALPS_CYCLED, NAN);
-            return;
-        }
-        if (phase == 1) {
-            // leaving row: most negative RHS, strict <, first wins (src/simplex.ts:111-119)
-            KI b = {INFINITY, INT_MAX};
-            for (int r = 1 + tid; r < h; r += nt) {
-                const double v = d.rhs[r];
-                if (v < -precision && ki_better(v, r, b.k, b.i)) {
-                    b.k = v;
-                    b.i = r;
-                }
-            }
-            b = block_argmin(b, sk, si);
-            if (b.i == INT_MAX) { // :120 tail call of phase2 -- fresh counter and history
-                phase = 2;
-                iter = 0.0;
-                la_valid = false;
-                if (tid == 0) st->hist_len = 0;
-                continue;
-            }
-            row = b.i;
-            // entering column: max -M[0,c]/M[row,c] over M[row,c] < -precision (:123-134)
-            const double *mrow = d.mat + (size_t)row * d.pitch;
-            KI e = {INFINITY, INT_MAX};
-            for (int c = 1 + tid; c < w; c += nt) {
-                const double coefficient = mrow[c];
-                if (coefficient < -precision) {
-                    const double ratio = -d.mat[c] / coefficient;
-                    if (ratio > -INFINITY && ki_better(-ratio, c, e.k, e.i)) {
-                        e.k = -ratio;
-                        e.i = c;
-                    }
-                }
-            }
-            e = block_argmin(e, sk, si);
-            if (e.i == INT_MAX) { // :135
-                finish(st, YALPS_INFEASIBLE, NAN);
-                return;
-            }
-            col = e.i;
-            gather_column(d, h, col, d.cbuf[cur]);
-            break;
-        } else {
-            // entering column: Dantzig pricing (src/simplex.ts:71-79), normally already known
-            if (la_valid) {
-                col = la;
-                cur ^= 1;
-            } else {
-                KI p = {INFINITY, INT_MAX};
-                for (int c = 1 + tid; c < w; c += nt) {
-                    const double rc = d.mat[c];
-                    if (rc > precision && ki_better(-rc, c, p.k, p.i)) {
-                        p.k = -rc;
-                        p.i = c;
-                    }
-                }
-                p = block_argmin(p, sk, si);
-                col = p.i == INT_MAX ? 0 : p.i;
-                if (col) gather_column(d, h, col, d.cbuf[cur]);
-            }
-            if (col == 0) { // :80
-                finish(st, YALPS_OPTIMAL, round_to_precision(d.mat[0], precision));
-                return;
-            }
-            // leaving row: min-ratio test with the early break (:83-95).  Closed form: the
-            // lowest-index eligible row whose ratio is <= precision if there is one (key -inf),
-            // else the lowest-index arg-min.
-            const double *cb = d.cbuf[cur];
-            KI b = {INFINITY, INT_MAX};
-            for (int r = 1 + tid; r < h; r += nt) {
-                const double value = cb[r];
-                if (value <= precision) continue;
-                const double ratio = d.rhs[r] / value;
-                if (!(ratio < INFINITY)) continue;
-                const double key = (ratio <= precision) ? -INFINITY : ratio;
-                if (ki_better(key, r, b.k, b.i)) {
-                    b.k = key;
-                    b.i = r;
-                }
-            }
-            b = block_argmin(b, sk, si);
-            if (b.i == INT_MAX) { // :96
-                finish(st, YALPS_UNBOUNDED, (double)col);
-                return;
-            }
-            row = b.i;
-            break;
-        }
-    }
-
-    if (st->check_cycles) { // :98,137
-        if (st->hist_len >= st->hist_cap) {
-            // history full: leave the state untouched except for the phase switch, which is
-            // idempotent, and let the host grow the buffers
-            if (tid == 0) {
-                st->pause = 1;
-                st->pending = 0;
-                if (phase != st->phase) {
-                    st->phase = phase;
-                    st->iter = iter;
-                    st->la_valid = 0;
-                }
-            }
-            return;
-        }
-        const bool cyc = has_cycle(st, d.var[w + row], d.var[col], &cyc_flag);
-        if (tid == 0) st->hist_len = st->hist_len + 1;
-        if (cyc) {
-            finish(st, YALPS_CYCLED, NAN);
-            return;
-        }
-    }
-
-    if (tid == 0) st->cur = cur; // prepare_pivot mirrors into cbuf[cur ^ 1]
-    __syncthreads();
-    const int next = prepare_pivot(d, st, row, col, d.cbuf[cur], phase == 2, precision, sk, si);
-    if (tid == 0) {
-        st->phase = phase;
-        st->row = row;
-        st->col = col;
-        st->la = next;
-        st->la_valid = phase == 2;
-        st->rhs_valid = 1;
-        st->iter = iter + 1.0;
-        st->pivots = st->pivots + 1;
-        st->pending = 1;
-    }
-}
-
-// One explicit pivot (yalps_tableau_pivot / bench): same preparation, no scans.
-__global__ __launch_bounds__(SELECT_THREADS) void prepare_kernel(Desc d, int row, int col) {
-    __shared__ double sk[16];
-    __shared__ int si[16];
-    YState *st = d.st;
-    gather_column(d, st->height, col, d.cbuf[st->cur]);
-    prepare_pivot(d, st, row, col, d.cbuf[st->cur], false, 0.0, sk, si);
-    if (threadIdx.x == 0) {
-        st->row = row;
-        st->col = col;
-        st->la = 0;
-        st->la_valid = 0;
-        st->pending = 1;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// sweep_kernel: row elimination, src/simplex.ts:27-38.  HBM-bound rank-1 update.
-// grid = (column blocks of 512 doubles, row groups); lane = one 16-byte unit of a row; a block
-// walks rows rg, rg + RG, ... with SWEEP_ROWS loads in flight per lane.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(SWEEP_THREADS) void sweep_kernel(Desc d, int force) {
-    const YState *st = d.st;
-    if (!force && (st->status != RUNNING || !st->pending)) return;
-    const int c0 = (blockIdx.x * SWEEP_THREADS + threadIdx.x) * 2;
-    if (c0 >= d.w) return;
-    const int h = st->height, row = st->row, col = st->col;
-    const int la = (st->la_valid && st->la > 0) ? st->la : -1;
-    const double q = st->quotient;
-    const int cur = st->cur;
-    const double *__restrict__ ccol = d.cbuf[cur];
-    double *__restrict__ ncol = d.cbuf[cur ^ 1];
-    const int pitch = d.pitch;
-
-    const double2 p = *reinterpret_cast<const double2 *>(d.prow + c0);
-    const bool f0 = (unsigned long long)__double_as_longlong(p.x) != FLUSHED;
-    const bool f1 = (unsigned long long)__double_as_longlong(p.y) != FLUSHED;
-    const bool has_col = (col >> 1) == (c0 >> 1);
-    const bool block_has_col = (col >> 9) == (int)blockIdx.x;
-    const bool has_la = la >= 0 && (la >> 1) == (c0 >> 1);
-    const int RG = gridDim.y;
-
-    for (int rbase = blockIdx.y; rbase < h; rbase += RG * SWEEP_ROWS) {
-        double coef[SWEEP_ROWS];
-        bool live[SWEEP_ROWS], act[SWEEP_ROWS];
-        double2 v[SWEEP_ROWS];
-#pragma unroll
-        for (int g = 0; g < SWEEP_ROWS; g++) {
-            const int r = rbase + g * RG;
-            live[g] = r < h && r != row;
-            coef[g] = live[g] ? ccol[r] : 0.0;
-            act[g] = live[g] && fabs(coef[g]) > 1e-16; // rows with |coef| <= 1e-16 stay untouched
-        }
-#pragma unroll
-        for (int g = 0; g < SWEEP_ROWS; g++) {
-            const int r = rbase + g * RG;
-            if (act[g]) v[g] = *reinterpret_cast<const double2 *>(d.mat + (size_t)r * pitch + c0);
-        }
-#pragma unroll
-        for (int g = 0; g < SWEEP_ROWS; g++) {
-            const int r = rbase + g * RG;
-            if (act[g]) {
-                double *mp = d.mat + (size_t)r * pitch + c0;
-                const double c = coef[g];
-                double2 o = v[g];
-                if (f0) {
-                    const double prod = c * p.x;
-                    o.x = o.x - prod;
-                }
-                if (f1) {
-                    const double prod = c * p.y;
-                    o.y = o.y - prod;
-                }
-                if (block_has_col) {
-                    const double nq = -c / q;
-                    if (has_col) {
-                        if (col & 1)
-                            o.y = nq;
-                        else
-                            o.x = nq;
-                    }
-                }
-                *reinterpret_cast<double2 *>(mp) = o;
-                if (c0 == 0) d.rhs[r] = o.x;
-                if (has_la) ncol[r] = (la & 1) ? o.y : o.x;
-            } else if (live[g] && has_la) {
-                ncol[r] = d.mat[(size_t)r * pitch + la];
-            }
-        }
+        S->swap_valid = 0;
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+using KernelFn = void (*)(Desc, int, int, int);
+
+struct Variant {
+    int T, J, R;
+    KernelFn fn;
+};
+
+#define VARIANT(T, J, R, D) {T, J, R, pivot_kernel<T, J, R, D>}
+const Variant kVariants[] = {
+    VARIANT(256, 1, 4, 4),   VARIANT(256, 1, 9, 9),  VARIANT(256, 1, 16, 8),  VARIANT(256, 2, 4, 4),
+    VARIANT(256, 2, 8, 8),   VARIANT(1024, 1, 4, 4), VARIANT(1024, 1, 9, 9), VARIANT(1024, 1, 16, 8),
+    VARIANT(1024, 2, 4, 4),  VARIANT(1024, 2, 8, 8), VARIANT(1024, 4, 4, 2), VARIANT(1024, 8, 2, 1),
+};
+#undef VARIANT
+
 thread_local std::string g_err;
 
 int fail(int code, const std::string &msg) {
@@ -498,6 +763,11 @@ int fail(int code, const std::string &msg) {
                         std::string(#expr) + ": " + hipGetErrorString(e_));                       \
     } while (0)
 
+int env_int(const char *name, int dflt) {
+    const char *e = std::getenv(name);
+    return (e && *e) ? std::atoi(e) : dflt;
+}
+
 } // namespace
 
 struct yalps_ctx {
@@ -505,15 +775,19 @@ struct yalps_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool eager = false;
+    bool nt_stores = false;
+    int max_blocks = 256; // workgroups per launch (one per CU by default)
 };
 
 struct yalps_tableau {
     yalps_ctx *ctx = nullptr;
     Desc d{};
     int32_t height = 0;
-    dim3 sweep_grid;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
+    int cur = 0; // tableau buffer holding the current tableau
+    Variant var{};
+    int nb = 1;
+    hipGraph_t graph[2] = {nullptr, nullptr}; // [0] fused, [1] decide/apply (checkCycles)
+    hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
     YState *host_state = nullptr; // pinned, 4 rotating slots
     hipEvent_t slot_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int32_t *hist[2] = {nullptr, nullptr};
@@ -522,35 +796,39 @@ struct yalps_tableau {
 
 namespace {
 
-int launch_pair_batch(yalps_tableau *t, int pairs) {
-    hipStream_t s = t->ctx->stream;
-    for (int i = 0; i < pairs; i++) {
-        hipLaunchKernelGGL(select_kernel, dim3(1), dim3(SELECT_THREADS), 0, s, t->d);
-        hipLaunchKernelGGL(sweep_kernel, t->sweep_grid, dim3(SWEEP_THREADS), 0, s, t->d, 0);
+void launch_one(yalps_tableau *t, int parity, int mode, int force) {
+    const int grid = mode == MODE_DECIDE ? 1 : t->nb;
+    t->var.fn<<<dim3(grid), dim3(t->var.T), 0, t->ctx->stream>>>(t->d, parity, mode, force);
+}
+
+int launch_batch(yalps_tableau *t, int which) {
+    for (int i = 0; i < LAUNCHES_PER_GRAPH; i++) {
+        const int mode = which == 0 ? MODE_FUSED : ((i & 1) ? MODE_DECIDE : MODE_APPLY);
+        launch_one(t, i & 1, mode, t->ctx->nt_stores ? 64 : 0);
     }
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-int ensure_graph(yalps_tableau *t) {
-    if (t->graph_exec || t->ctx->eager) return 0;
+int ensure_graph(yalps_tableau *t, int which) {
+    if (t->graph_exec[which] || t->ctx->eager) return 0;
     hipStream_t s = t->ctx->stream;
     HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    int rc = launch_pair_batch(t, PAIRS_PER_GRAPH);
-    hipError_t e = hipStreamEndCapture(s, &t->graph);
+    int rc = launch_batch(t, which);
+    hipError_t e = hipStreamEndCapture(s, &t->graph[which]);
     if (rc) return rc;
     HIP_TRY(e);
-    HIP_TRY(hipGraphInstantiate(&t->graph_exec, t->graph, nullptr, nullptr, 0));
+    HIP_TRY(hipGraphInstantiate(&t->graph_exec[which], t->graph[which], nullptr, nullptr, 0));
     return 0;
 }
 
-int run_batch(yalps_tableau *t) {
-    if (t->ctx->eager) return launch_pair_batch(t, PAIRS_PER_GRAPH);
-    HIP_TRY(hipGraphLaunch(t->graph_exec, t->ctx->stream));
+int run_batch(yalps_tableau *t, int which) {
+    if (t->ctx->eager) return launch_batch(t, which);
+    HIP_TRY(hipGraphLaunch(t->graph_exec[which], t->ctx->stream));
     return 0;
 }
 
-int grow_history(yalps_tableau *t, int64_t need, const YState *cur_state) {
+int grow_history(yalps_tableau *t, int64_t need, int64_t keep) {
     int64_t cap = t->hist_cap ? t->hist_cap : 4096;
     while (cap < need) cap *= 2;
     if (cap == t->hist_cap) return 0;
@@ -558,14 +836,48 @@ int grow_history(yalps_tableau *t, int64_t need, const YState *cur_state) {
     for (int k = 0; k < 2; k++) {
         int32_t *nb = nullptr;
         HIP_TRY(hipMalloc(&nb, sizeof(int32_t) * (size_t)cap));
-        if (t->hist[k] && cur_state && cur_state->hist_len > 0)
-            HIP_TRY(hipMemcpyAsync(nb, t->hist[k], sizeof(int32_t) * (size_t)cur_state->hist_len,
-                                   hipMemcpyDeviceToDevice, s));
+        if (t->hist[k] && keep > 0)
+            HIP_TRY(hipMemcpyAsync(nb, t->hist[k], sizeof(int32_t) * (size_t)keep, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipStreamSynchronize(s));
         if (t->hist[k]) HIP_TRY(hipFree(t->hist[k]));
         t->hist[k] = nb;
     }
     t->hist_cap = cap;
+    return 0;
+}
+
+int init_state(yalps_tableau *t, double precision, double maxPivots, int32_t checkCycles) {
+    hipStream_t s = t->ctx->stream;
+    if (checkCycles && !t->hist_cap) {
+        int rc = grow_history(t, 4096, 0);
+        if (rc) return rc;
+    }
+    if (t->cur != 0) { // FUSED graphs derive the buffer index from the launch parity: start from 0
+        const Desc &d = t->d;
+        HIP_TRY(hipMemcpyAsync(d.mat[0], d.mat[1], sizeof(double) * (size_t)d.pitch * t->height,
+                               hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d.rhs[0], d.rhs[1], sizeof(double) * (size_t)t->height, hipMemcpyDeviceToDevice, s));
+        t->cur = 0;
+    }
+    YConst hc;
+    std::memset(&hc, 0, sizeof hc);
+    hc.height = t->height;
+    hc.check_cycles = checkCycles ? 1 : 0;
+    hc.hist_cap = t->hist_cap;
+    hc.hist_leaving = t->hist[0];
+    hc.hist_entering = t->hist[1];
+    hc.precision = precision;
+    hc.max_pivots = maxPivots;
+    HIP_TRY(hipMemcpyAsync(t->d.cst, &hc, sizeof(YConst), hipMemcpyHostToDevice, s));
+    YState *hs = &t->host_state[0];
+    std::memset(hs, 0, sizeof(YState));
+    hs->status = RUNNING;
+    hs->phase = 1;
+    hs->bootstrap = 1;
+    hs->mbuf = t->cur;
+    hs->result = NAN;
+    HIP_TRY(hipMemcpyAsync(t->d.st, hs, sizeof(YState), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s)); // slot 0 is reused by the polling loop
     return 0;
 }
 
@@ -621,8 +933,11 @@ int32_t yalps_ctx_create(int32_t device, yalps_ctx **out) {
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
-    const char *e = std::getenv("YALPS_HIP_EAGER");
-    c->eager = e && *e && *e != '0';
+    c->eager = env_int("YALPS_HIP_EAGER", 0) != 0;
+    c->nt_stores = env_int("YALPS_HIP_NT", 1) != 0; // measured 1-2 % faster in the pivot loop at 2049^2 and 4097^2
+    c->max_blocks = env_int("YALPS_HIP_BLOCKS", prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+    if (c->max_blocks < 1) c->max_blocks = 1;
+    if (c->max_blocks > MAX_BLOCKS) c->max_blocks = MAX_BLOCKS;
     *out = c;
     return 0;
 }
@@ -639,34 +954,55 @@ void yalps_ctx_destroy(yalps_ctx *c) {
 int32_t yalps_tableau_create(yalps_ctx *ctx, int32_t width, int32_t hcap, yalps_tableau **out) {
     if (!ctx || !out || width < 1 || hcap < 1) return fail(YALPS_E_ARG, "yalps_tableau_create: bad argument");
     if ((int64_t)width + hcap > INT32_MAX / 2) return fail(YALPS_E_ARG, "tableau too large");
+    const int n = width - 1, units = (n + 1) / 2;
+    // kernel variant: lanes x units-per-lane must span the row; rows in flight sized so that
+    // one workgroup per CU covers the tableau in one batch when it can
+    int T = units <= 512 ? 256 : 1024;
+    int J = 1;
+    while (T * J < units) J *= 2;
+    if (J > 8) return fail(YALPS_E_ARG, "width > 16385 columns is not supported by this build");
     HIP_TRY(hipSetDevice(ctx->device));
     yalps_tableau *t = new yalps_tableau();
     t->ctx = ctx;
+    const int forceR = env_int("YALPS_HIP_ROWS", 0);
+    // spread the rows over all workgroups; rows in flight per lane R >= rows per workgroup if any
+    // variant allows it (one batch per launch), else the largest R (several batches)
+    t->nb = hcap < ctx->max_blocks ? hcap : ctx->max_blocks;
+    const int rows_per_block = (hcap + t->nb - 1) / t->nb;
+    const Variant *pick = nullptr;
+    for (const Variant &v : kVariants) {
+        if (v.T != T || v.J != J) continue;
+        pick = &v; // candidates are listed by increasing R
+        if (v.R >= (forceR ? forceR : rows_per_block)) break;
+    }
+    t->var = *pick;
+
     Desc &d = t->d;
     d.w = width;
+    d.n = n;
     d.hcap = hcap;
-    d.pitch = (width + 15) / 16 * 16; // 128-byte rows
+    d.nb = t->nb;
+    d.pitch = (n + 15) / 16 * 16; // 128-byte rows
+    if (d.pitch < 16) d.pitch = 16;
     const size_t mat_bytes = sizeof(double) * (size_t)d.pitch * hcap;
-    HIP_TRY(hipMalloc(&d.mat, mat_bytes));
-    HIP_TRY(hipMemsetAsync(d.mat, 0, mat_bytes, ctx->stream));
-    for (int k = 0; k < 2; k++) HIP_TRY(hipMalloc(&d.cbuf[k], sizeof(double) * (size_t)hcap));
-    HIP_TRY(hipMalloc(&d.rhs, sizeof(double) * (size_t)hcap));
-    HIP_TRY(hipMalloc(&d.prow, sizeof(double) * (size_t)d.pitch));
-    HIP_TRY(hipMemsetAsync(d.prow, 0, sizeof(double) * (size_t)d.pitch, ctx->stream));
+    hipStream_t s = ctx->stream;
+    for (int k = 0; k < 2; k++) {
+        HIP_TRY(hipMalloc(&d.mat[k], mat_bytes));
+        HIP_TRY(hipMemsetAsync(d.mat[k], 0, mat_bytes, s));
+        HIP_TRY(hipMalloc(&d.rhs[k], sizeof(double) * (size_t)hcap));
+    }
     HIP_TRY(hipMalloc(&d.pos, sizeof(int32_t) * (size_t)(width + hcap)));
     HIP_TRY(hipMalloc(&d.var, sizeof(int32_t) * (size_t)(width + hcap)));
-    HIP_TRY(hipMalloc(&d.st, sizeof(YState)));
-    HIP_TRY(hipMemsetAsync(d.st, 0, sizeof(YState), ctx->stream));
+    HIP_TRY(hipMalloc(&d.st, sizeof(YState) * 2));
+    HIP_TRY(hipMemsetAsync(d.st, 0, sizeof(YState) * 2, s));
+    HIP_TRY(hipMalloc(&d.cst, sizeof(YConst)));
+    for (int k = 0; k < 2; k++) {
+        HIP_TRY(hipMalloc(&d.part_ratio[k], sizeof(Part) * MAX_BLOCKS));
+        HIP_TRY(hipMalloc(&d.part_rhs[k], sizeof(Part) * MAX_BLOCKS));
+    }
     HIP_TRY(hipHostMalloc(&t->host_state, sizeof(YState) * 4, hipHostMallocDefault));
     for (int k = 0; k < 4; k++) HIP_TRY(hipEventCreateWithFlags(&t->slot_ev[k], hipEventDisableTiming));
-    // sweep grid: column blocks x row groups, ~8 rows per lane, capped near 2048 workgroups
-    const int col_blocks = ((width + 1) / 2 + SWEEP_THREADS - 1) / SWEEP_THREADS;
-    int rg = (hcap + SWEEP_ROWS - 1) / SWEEP_ROWS;
-    const int max_rg = (2048 + col_blocks - 1) / col_blocks;
-    if (rg > max_rg) rg = max_rg;
-    if (rg < 1) rg = 1;
-    t->sweep_grid = dim3(col_blocks, rg, 1);
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipStreamSynchronize(s));
     *out = t;
     return 0;
 }
@@ -675,12 +1011,15 @@ void yalps_tableau_destroy(yalps_tableau *t) {
     if (!t) return;
     (void)hipSetDevice(t->ctx->device);
     (void)hipStreamSynchronize(t->ctx->stream);
-    if (t->graph_exec) (void)hipGraphExecDestroy(t->graph_exec);
-    if (t->graph) (void)hipGraphDestroy(t->graph);
+    for (int k = 0; k < 2; k++) {
+        if (t->graph_exec[k]) (void)hipGraphExecDestroy(t->graph_exec[k]);
+        if (t->graph[k]) (void)hipGraphDestroy(t->graph[k]);
+    }
     Desc &d = t->d;
-    void *bufs[] = {d.mat, d.cbuf[0], d.cbuf[1], d.rhs, d.prow, d.pos, d.var, d.st, t->hist[0], t->hist[1]};
-    for (void *b : bufs)
-        if (b) (void)hipFree(b);
+    void *bufs[] = {d.mat[0], d.mat[1], d.rhs[0], d.rhs[1], d.pos, d.var, d.st, d.cst, d.part_ratio[0], d.part_ratio[1], d.part_rhs[0], d.part_rhs[1],
+                    t->hist[0], t->hist[1]};
+    for (void *p : bufs)
+        if (p) (void)hipFree(p);
     if (t->host_state) (void)hipHostFree(t->host_state);
     for (auto &e : t->slot_ev)
         if (e) (void)hipEventDestroy(e);
@@ -696,8 +1035,13 @@ int32_t yalps_tableau_upload(yalps_tableau *t, const double *matrix, int32_t hei
     HIP_TRY(hipSetDevice(t->ctx->device));
     hipStream_t s = t->ctx->stream;
     const Desc &d = t->d;
-    HIP_TRY(hipMemcpy2DAsync(d.mat, sizeof(double) * d.pitch, matrix, sizeof(double) * d.w, sizeof(double) * d.w,
-                             height, hipMemcpyHostToDevice, s));
+    // split: column 0 -> rhs[], columns 1..w-1 -> mat[][pitch]
+    t->cur = 0;
+    HIP_TRY(hipMemcpy2DAsync(d.rhs[0], sizeof(double), matrix, sizeof(double) * d.w, sizeof(double), height,
+                             hipMemcpyHostToDevice, s));
+    if (d.n > 0)
+        HIP_TRY(hipMemcpy2DAsync(d.mat[0], sizeof(double) * d.pitch, matrix + 1, sizeof(double) * d.w,
+                                 sizeof(double) * d.n, height, hipMemcpyHostToDevice, s));
     const size_t nperm = sizeof(int32_t) * (size_t)(d.w + height);
     HIP_TRY(hipMemcpyAsync(d.pos, pos, nperm, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d.var, var, nperm, hipMemcpyHostToDevice, s));
@@ -711,9 +1055,13 @@ int32_t yalps_tableau_download(yalps_tableau *t, double *matrix, int32_t *pos, i
     HIP_TRY(hipSetDevice(t->ctx->device));
     hipStream_t s = t->ctx->stream;
     const Desc &d = t->d;
-    if (matrix)
-        HIP_TRY(hipMemcpy2DAsync(matrix, sizeof(double) * d.w, d.mat, sizeof(double) * d.pitch,
-                                 sizeof(double) * d.w, t->height, hipMemcpyDeviceToHost, s));
+    if (matrix) {
+        HIP_TRY(hipMemcpy2DAsync(matrix, sizeof(double) * d.w, d.rhs[t->cur], sizeof(double), sizeof(double),
+                                 t->height, hipMemcpyDeviceToHost, s));
+        if (d.n > 0)
+            HIP_TRY(hipMemcpy2DAsync(matrix + 1, sizeof(double) * d.w, d.mat[t->cur], sizeof(double) * d.pitch,
+                                     sizeof(double) * d.n, t->height, hipMemcpyDeviceToHost, s));
+    }
     const size_t nperm = sizeof(int32_t) * (size_t)(d.w + t->height);
     if (pos) HIP_TRY(hipMemcpyAsync(pos, d.pos, nperm, hipMemcpyDeviceToHost, s));
     if (var) HIP_TRY(hipMemcpyAsync(var, d.var, nperm, hipMemcpyDeviceToHost, s));
@@ -725,9 +1073,7 @@ int32_t yalps_tableau_download_rhs(yalps_tableau *t, double *col0) {
     if (!t || !col0) return fail(YALPS_E_ARG, "yalps_tableau_download_rhs: NULL argument");
     HIP_TRY(hipSetDevice(t->ctx->device));
     hipStream_t s = t->ctx->stream;
-    const Desc &d = t->d;
-    HIP_TRY(hipMemcpy2DAsync(col0, sizeof(double), d.mat, sizeof(double) * d.pitch, sizeof(double), t->height,
-                             hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(col0, t->d.rhs[t->cur], sizeof(double) * (size_t)t->height, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return 0;
 }
@@ -738,7 +1084,10 @@ int32_t yalps_tableau_copy(yalps_tableau *dst, const yalps_tableau *src) {
         return fail(YALPS_E_ARG, "yalps_tableau_copy: incompatible tableaux");
     HIP_TRY(hipSetDevice(dst->ctx->device));
     hipStream_t s = dst->ctx->stream;
-    HIP_TRY(hipMemcpyAsync(dst->d.mat, src->d.mat, sizeof(double) * (size_t)src->d.pitch * src->height,
+    dst->cur = 0;
+    HIP_TRY(hipMemcpyAsync(dst->d.mat[0], src->d.mat[src->cur], sizeof(double) * (size_t)src->d.pitch * src->height,
+                           hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(dst->d.rhs[0], src->d.rhs[src->cur], sizeof(double) * (size_t)src->height,
                            hipMemcpyDeviceToDevice, s));
     const size_t nperm = sizeof(int32_t) * (size_t)(src->d.w + src->height);
     HIP_TRY(hipMemcpyAsync(dst->d.pos, src->d.pos, nperm, hipMemcpyDeviceToDevice, s));
@@ -748,45 +1097,24 @@ int32_t yalps_tableau_copy(yalps_tableau *dst, const yalps_tableau *src) {
     return 0;
 }
 
-static int32_t init_state(yalps_tableau *t, double precision, double maxPivots, int32_t checkCycles) {
-    hipStream_t s = t->ctx->stream;
-    if (checkCycles && !t->hist_cap) {
-        int rc = grow_history(t, 4096, nullptr);
-        if (rc) return rc;
-    }
-    YState *hs = &t->host_state[0];
-    std::memset(hs, 0, sizeof(YState));
-    hs->status = RUNNING;
-    hs->phase = 1;
-    hs->height = t->height;
-    hs->check_cycles = checkCycles ? 1 : 0;
-    hs->hist_cap = t->hist_cap;
-    hs->hist_leaving = t->hist[0];
-    hs->hist_entering = t->hist[1];
-    hs->precision = precision;
-    hs->max_pivots = maxPivots;
-    hs->result = NAN;
-    HIP_TRY(hipMemcpyAsync(t->d.st, hs, sizeof(YState), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s)); // slot 0 is reused below
-    return 0;
-}
-
 int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots, int32_t checkCycles,
                             double *result_out, int64_t *pivots_out, float *gpu_ms_out) {
     if (!t || t->height < 1) return fail(YALPS_E_ARG, "yalps_tableau_solve: no tableau uploaded");
     yalps_ctx *c = t->ctx;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = c->stream;
+    const int which = checkCycles ? 1 : 0;
     int rc = init_state(t, precision, maxPivots, checkCycles);
     if (rc) return rc;
-    rc = ensure_graph(t);
+    rc = ensure_graph(t, which);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(c->ev0, s));
     // keep one batch in flight while the previous batch's state is inspected
     YState fin;
+    std::memset(&fin, 0, sizeof fin);
     int issued = 0, checked = 0;
     for (;;) {
-        rc = run_batch(t);
+        rc = run_batch(t, which);
         if (rc) return rc;
         const int slot = issued & 3;
         HIP_TRY(hipMemcpyAsync(&t->host_state[slot], t->d.st, sizeof(YState), hipMemcpyDeviceToHost, s));
@@ -811,50 +1139,67 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
                 fin = now;
                 break;
             }
-            rc = grow_history(t, now.hist_cap * 2, &now);
+            rc = grow_history(t, t->hist_cap * 2, now.hist_len);
             if (rc) return rc;
+            YConst hc;
+            HIP_TRY(hipMemcpy(&hc, t->d.cst, sizeof(YConst), hipMemcpyDeviceToHost));
+            hc.hist_cap = t->hist_cap;
+            hc.hist_leaving = t->hist[0];
+            hc.hist_entering = t->hist[1];
+            HIP_TRY(hipMemcpy(t->d.cst, &hc, sizeof(YConst), hipMemcpyHostToDevice));
             now.pause = 0;
-            now.hist_cap = t->hist_cap;
-            now.hist_leaving = t->hist[0];
-            now.hist_entering = t->hist[1];
             HIP_TRY(hipMemcpy(t->d.st, &now, sizeof(YState), hipMemcpyHostToDevice));
         }
     }
     HIP_TRY(hipEventRecord(c->ev1, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (gpu_ms_out) HIP_TRY(hipEventElapsedTime(gpu_ms_out, c->ev0, c->ev1));
+    t->cur = fin.mbuf;
     if (result_out) *result_out = fin.result;
     if (pivots_out) *pivots_out = fin.pivots;
     return fin.status;
 }
 
+static int32_t set_decision(yalps_tableau *t, int32_t row, int32_t col) {
+    int rc = init_state(t, 1e-8, INFINITY, 0);
+    if (rc) return rc;
+    YState *hs = &t->host_state[0];
+    hs->bootstrap = 0;
+    hs->phase = 1; // no pricing consequences: APPLY only normalises and eliminates
+    hs->dec_valid = 1;
+    hs->dec_row = row;
+    hs->dec_col = col;
+    HIP_TRY(hipMemcpy(t->d.st, hs, sizeof(YState), hipMemcpyHostToDevice));
+    return 0;
+}
+
 int32_t yalps_tableau_pivot(yalps_tableau *t, int32_t row, int32_t col) {
     if (!t || t->height < 1) return fail(YALPS_E_ARG, "yalps_tableau_pivot: no tableau uploaded");
-    if (row < 0 || row >= t->height || col < 0 || col >= t->d.w) return fail(YALPS_E_ARG, "pivot out of range");
+    if (row < 0 || row >= t->height || col < 1 || col >= t->d.w) return fail(YALPS_E_ARG, "pivot out of range");
     HIP_TRY(hipSetDevice(t->ctx->device));
-    int rc = init_state(t, 1e-8, 0.0, 0);
+    int rc = set_decision(t, row, col);
     if (rc) return rc;
-    hipStream_t s = t->ctx->stream;
-    hipLaunchKernelGGL(prepare_kernel, dim3(1), dim3(SELECT_THREADS), 0, s, t->d, row, col);
-    hipLaunchKernelGGL(sweep_kernel, t->sweep_grid, dim3(SWEEP_THREADS), 0, s, t->d, 0);
+    launch_one(t, 0, MODE_APPLY, 0);
+    flush_swap_kernel<<<dim3(1), dim3(64), 0, t->ctx->stream>>>(t->d, 1);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipStreamSynchronize(t->ctx->stream));
+    t->cur ^= 1; // the pivot wrote the other buffer
     return 0;
 }
 
 int32_t yalps_tableau_bench_sweep(yalps_tableau *t, int32_t row, int32_t col, int32_t launches, float *avg_us_out) {
     if (!t || t->height < 1 || launches < 1) return fail(YALPS_E_ARG, "yalps_tableau_bench_sweep: bad argument");
-    if (row < 0 || row >= t->height || col < 0 || col >= t->d.w) return fail(YALPS_E_ARG, "pivot out of range");
+    if (row < 0 || row >= t->height || col < 1 || col >= t->d.w) return fail(YALPS_E_ARG, "pivot out of range");
     yalps_ctx *c = t->ctx;
     HIP_TRY(hipSetDevice(c->device));
-    int rc = init_state(t, 1e-8, 0.0, 0);
+    int rc = set_decision(t, row, col);
     if (rc) return rc;
     hipStream_t s = c->stream;
-    hipLaunchKernelGGL(prepare_kernel, dim3(1), dim3(SELECT_THREADS), 0, s, t->d, row, col);
-    for (int i = 0; i < 3; i++) hipLaunchKernelGGL(sweep_kernel, t->sweep_grid, dim3(SWEEP_THREADS), 0, s, t->d, 1);
+    // force=1: the state is left untouched, so every launch re-applies the same pivot
+    const int fl = 1 | (c->nt_stores ? 64 : 0);
+    for (int i = 0; i < 3; i++) launch_one(t, 0, MODE_APPLY, fl);
     HIP_TRY(hipEventRecord(c->ev0, s));
-    for (int i = 0; i < launches; i++)
-        hipLaunchKernelGGL(sweep_kernel, t->sweep_grid, dim3(SWEEP_THREADS), 0, s, t->d, 1);
+    for (int i = 0; i < launches; i++) launch_one(t, 0, MODE_APPLY, fl);
     HIP_TRY(hipEventRecord(c->ev1, s));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
@@ -879,12 +1224,11 @@ int32_t yalps_simplex_f64_ex(double *matrix, int32_t width, int32_t height, int3
     std::lock_guard<std::mutex> lock(g_default_mu);
     int rc;
     if (!g_default_ctx) {
-        const char *dev = std::getenv("YALPS_HIP_DEVICE");
-        rc = yalps_ctx_create(dev ? std::atoi(dev) : 0, &g_default_ctx);
+        rc = yalps_ctx_create(env_int("YALPS_HIP_DEVICE", 0), &g_default_ctx);
         if (rc) return rc;
     }
     yalps_tableau *t = g_default_tab;
-    if (!t || t->d.w != width || t->d.hcap < height) {
+    if (!t || t->d.w != width || t->d.hcap < height || t->d.hcap > 4 * height) {
         if (t) yalps_tableau_destroy(t);
         g_default_tab = nullptr;
         rc = yalps_tableau_create(g_default_ctx, width, height, &t);
@@ -915,3 +1259,4 @@ int32_t yalps_simplex_f64(double *matrix, int32_t width, int32_t height, int32_t
 }
 
 } // extern "C"
+
