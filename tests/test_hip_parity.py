@@ -123,3 +123,33 @@ def test_bad_arguments_fail_loudly(nat, ctx):
             t.upload(np.zeros(4 * 9), 9, np.arange(13, dtype=np.int32), np.arange(13, dtype=np.int32))
     finally:
         t.close()
+
+
+# ---- end to end: solve() with the HIP simplex behind it (reference test-suite semantics) --------
+from tests import _cases as K  # noqa: E402
+
+
+@pytest.mark.parametrize("name", K.names())
+def test_solve_matches_reference_cases(nat, oracle, name):
+    """solve(model, options) on the GPU reproduces the reference test-suite's expected status /
+    objective / feasibility for every case (tests/solver.ts:23-25, tests/additional/json.ts), and
+    equals the oracle-backed solve exactly (same host code, bit-identical simplex)."""
+    from tests.test_host_model import oracle_backend
+    from yalps_amd import solve as S
+    case = K.load(name)
+    sol = S.solve(case["model"], case["options"])
+    assert K.valid_solution_and_status(sol, case["expected"], case["model"], case["options"]), sol["status"]
+    ref = S._solve_with(oracle_backend(oracle), case["model"], case["options"])
+    assert sol["status"] == ref["status"] and G.same_number(sol["result"], ref["result"])
+    assert sol["variables"] == ref["variables"]
+
+
+def test_solve_readme_example(nat):
+    from yalps_amd import model as M
+    from yalps_amd import solve as S
+    model = {"direction": "maximize", "objective": "profit",
+             "constraints": {"wood": M.less_eq(300), "labor": M.less_eq(110), "storage": M.less_eq(400)},
+             "variables": {"table": {"wood": 30, "labor": 5, "profit": 1200, "storage": 30},
+                           "dresser": {"wood": 20, "labor": 10, "profit": 1600, "storage": 50}},
+             "integers": ["table", "dresser"]}
+    assert S.solve(model) == {"status": "optimal", "result": 14400.0, "variables": [("table", 8.0), ("dresser", 3.0)]}

@@ -1,0 +1,135 @@
+"""Best-first branch and bound over variable-bound cuts: host-side caller of the hot path,
+restating /root/reference/src/branchAndCut.ts:22-176.  Every node re-solves `root optimal
+tableau + cut rows` with simplex() (:126-127).
+
+Queue: the reference uses npm `heap` 0.2.7 (package.json:157), which is a port of Python's
+heapq; heapq with an eval-only ordering therefore pops ties in the same order.
+"""
+import heapq
+import math
+import time
+
+import numpy as np
+
+from .model import Tableau, TableauModel
+
+
+class _Branch:
+    __slots__ = ("eval", "cuts")
+
+    def __init__(self, ev, cuts):
+        self.eval, self.cuts = ev, cuts
+
+    def __lt__(self, other):  # comparator (x, y) => x[0] - y[0], :100
+        return self.eval < other.eval
+
+
+def _js_round(x):
+    f = math.floor(x)
+    return f + 1.0 if x - f >= 0.5 else float(f)
+
+
+def apply_cuts(tableau, buf, cuts):
+    """:22-61  new tableau = root tableau + one row per cut (sign, variable, value)."""
+    matrix, pos, var = buf
+    width, height = tableau.width, tableau.height
+    n = tableau.matrix.size
+    matrix[:n] = tableau.matrix
+    for i, (sign, variable, value) in enumerate(cuts):
+        r = (height + i) * width
+        p = int(tableau.position_of_variable[variable])
+        if p < width:
+            matrix[r] = sign * value
+            matrix[r + 1:r + width] = 0.0
+            matrix[r + p] = sign
+        else:
+            row = (p - width) * width
+            matrix[r] = sign * (value - matrix[row])
+            matrix[r + 1:r + width] = -sign * matrix[row + 1:row + width]
+    length = width + height + len(cuts)
+    pos[:width + height] = tableau.position_of_variable
+    var[:width + height] = tableau.variable_at_position
+    ext = np.arange(width + height, length, dtype=np.int32)
+    pos[width + height:length] = ext
+    var[width + height:length] = ext
+    return Tableau(matrix[:n + width * len(cuts)], width, height + len(cuts), pos[:length], var[:length])
+
+
+def most_fractional_var(tableau, int_vars):
+    """:64-85"""
+    highest, variable, value = 0.0, 0, 0.0
+    for int_var in int_vars:
+        row = int(tableau.position_of_variable[int_var]) - tableau.width
+        if row < 0:
+            continue
+        val = float(tableau.matrix[row * tableau.width])
+        frac = abs(val - _js_round(val))
+        if frac > highest:
+            highest, variable, value = frac, int_var, val
+    return variable, value, highest
+
+
+def branch_and_cut(simplex, tabmod, init_result, options):
+    """:89-176.  Returns (TableauModel of the best tableau, status, result)."""
+    tableau, sign, integers = tabmod.tableau, tabmod.sign, tabmod.integers
+    precision, max_iterations = options["precision"], options["maxIterations"]
+    tolerance, timeout = options["tolerance"], options["timeout"]
+    init_variable, init_value, init_frac = most_fractional_var(tableau, integers)
+    if init_frac <= precision:
+        return tabmod, "optimal", init_result
+
+    branches = []
+    heapq.heappush(branches, _Branch(init_result, [(-1, init_variable, float(math.ceil(init_value)))]))
+    heapq.heappush(branches, _Branch(init_result, [(1, init_variable, float(math.floor(init_value)))]))
+
+    max_extra_rows = len(integers) * 2
+    matrix_length = tableau.matrix.size + max_extra_rows * tableau.width
+    pos_var_length = tableau.position_of_variable.size + max_extra_rows
+
+    def new_buffer():
+        return (np.zeros(matrix_length, np.float64), np.zeros(pos_var_length, np.int32),
+                np.zeros(pos_var_length, np.int32))
+
+    candidate, solution_buf = new_buffer(), new_buffer()
+    optimal_threshold = init_result * (1.0 - sign * tolerance)
+    now = lambda: time.time() * 1000.0  # noqa: E731  Date.now()
+    stop_time = timeout + now()
+    timedout = now() >= stop_time
+    solution_found = False
+    best_eval = math.inf
+    best_tableau = tableau
+    it = 0
+    while it < max_iterations and branches and best_eval >= optimal_threshold and not timedout:
+        br = heapq.heappop(branches)
+        relaxed_eval, cuts = br.eval, br.cuts
+        if relaxed_eval > best_eval:
+            break
+        current = apply_cuts(tableau, candidate, cuts)
+        status, result = simplex(current, options)
+        if status == "optimal" and result < best_eval:
+            variable, value, frac = most_fractional_var(current, integers)
+            if frac <= precision:
+                solution_found = True
+                best_eval = result
+                best_tableau = current
+                candidate, solution_buf = solution_buf, candidate
+            else:
+                cuts_upper, cuts_lower = [], []
+                for cut in cuts:
+                    direction, v = cut[0], cut[1]
+                    if v == variable:
+                        (cuts_lower if direction < 0 else cuts_upper).append(cut)
+                    else:
+                        cuts_upper.append(cut)
+                        cuts_lower.append(cut)
+                cuts_lower.append((1, variable, float(math.floor(value))))
+                cuts_upper.append((-1, variable, float(math.ceil(value))))
+                heapq.heappush(branches, _Branch(result, cuts_upper))
+                heapq.heappush(branches, _Branch(result, cuts_lower))
+        timedout = now() >= stop_time
+        it += 1
+
+    unfinished = (timedout or it >= max_iterations) and bool(branches) and best_eval >= optimal_threshold
+    status = "timedout" if unfinished else ("infeasible" if not solution_found else "optimal")
+    return (TableauModel(best_tableau, sign, tabmod.variables, integers), status,
+            best_eval if solution_found else math.nan)

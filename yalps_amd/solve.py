@@ -1,0 +1,92 @@
+"""solve(model, options) -> Solution: the reference's public entry point
+(/root/reference/src/YALPS.ts:8-92) with the dense-tableau simplex running on the MI355X.
+
+Host side (model construction, branch and cut, result marshalling) mirrors the reference; the
+hot path -- `simplex(tableau, options)`, src/simplex.ts:144 -- is libyalps_hip.so.  There is no
+CPU fallback: without the HIP library and a gfx950 device `solve` raises.
+"""
+import math
+
+from . import _native
+from .branch_and_cut import branch_and_cut
+from .model import tableau_model
+
+# src/YALPS.ts:52-60
+_DEFAULTS = {
+    "precision": 1e-8,
+    "checkCycles": False,
+    "maxPivots": 8192,
+    "tolerance": 0,
+    "timeout": math.inf,
+    "maxIterations": 32768,
+    "includeZeroVariables": False,
+}
+
+default_options = dict(_DEFAULTS)  # a copy, like the reference's exported `defaultOptions` (:65)
+
+
+def round_to_precision(num, precision):
+    """src/util.ts:1-4 with JS Math.round (halves toward +infinity)."""
+    def js_round(x):
+        if x != x or math.isinf(x):
+            return x
+        f = math.floor(x)
+        return f + 1.0 if x - f >= 0.5 else float(f)
+    if precision == 0:
+        rounding = math.inf
+    else:
+        rounding = js_round(1.0 / precision)
+    v = (num + 2.220446049250313e-16) * rounding
+    if math.isinf(rounding):
+        return math.nan if (v != v or math.isinf(v)) else v / rounding
+    return js_round(v) / rounding
+
+
+def hip_simplex(tableau, options):
+    """The drop-in for src/simplex.ts:144 `simplex(tableau, options)`: in place, through the C ABI
+    (yalps_simplex_f64).  Returns (status, result)."""
+    status, result, _ = _native.simplex_host(
+        tableau.matrix, tableau.width, tableau.height, tableau.position_of_variable, tableau.variable_at_position,
+        precision=options["precision"], max_pivots=options["maxPivots"], check_cycles=options["checkCycles"])
+    return status, result
+
+
+def solution(tabmod, status, result, options):
+    """src/YALPS.ts:8-50"""
+    tableau, sign, vars_ = tabmod.tableau, tabmod.sign, tabmod.variables
+    precision = options["precision"]
+    if status == "optimal" or (status == "timedout" and not math.isnan(result)):
+        variables = []
+        for i, (key, _) in enumerate(vars_):
+            row = int(tableau.position_of_variable[i + 1]) - tableau.width
+            value = float(tableau.matrix[row * tableau.width]) if row >= 0 else 0.0
+            if value > precision:
+                variables.append((key, round_to_precision(value, precision)))
+            elif options["includeZeroVariables"]:
+                variables.append((key, 0.0))
+        return {"status": status, "result": -sign * result, "variables": variables}
+    if status == "unbounded":
+        variable = int(tableau.variable_at_position[int(result)]) - 1
+        return {"status": "unbounded", "result": sign * math.inf,
+                "variables": [(vars_[variable][0], math.inf)] if 0 <= variable < len(vars_) else []}
+    return {"status": status, "result": math.nan, "variables": []}  # infeasible | cycled | timedout w/o result
+
+
+def _solve_with(simplex, model, options=None):
+    """src/YALPS.ts:73-92 with the simplex backend as a parameter (tests drive the host logic
+    with the CPU oracle through this; the product binds the HIP backend below)."""
+    tabmod = tableau_model(model)
+    opt = dict(_DEFAULTS)
+    if options:
+        opt.update({k: v for k, v in options.items() if v is not None})
+    status, result = simplex(tabmod.tableau, opt)
+    if not tabmod.integers or status != "optimal":
+        return solution(tabmod, status, result, opt)
+    int_tabmod, int_status, int_result = branch_and_cut(simplex, tabmod, result, opt)
+    return solution(int_tabmod, int_status, int_result, opt)
+
+
+def solve(model, options=None):
+    """Runs the solver on `model` (see yalps_amd.model) with `options` (keys as in the reference's
+    `Options`, src/types.ts:203-265).  Returns {"status", "result", "variables": [(key, value)]}."""
+    return _solve_with(hip_simplex, model, options)
