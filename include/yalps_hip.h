@@ -70,6 +70,9 @@ typedef struct yalps_ctx yalps_ctx;
 typedef struct yalps_tableau yalps_tableau;
 
 int32_t yalps_ctx_create(int32_t device, yalps_ctx **out);
+/* Same, but every kernel / copy is enqueued on the caller's HIP stream (e.g. the stream a
+ * torch.distributed collective is ordered against). */
+int32_t yalps_ctx_create_on_stream(int32_t device, void *hip_stream, yalps_ctx **out);
 void yalps_ctx_destroy(yalps_ctx *ctx);
 
 /* A tableau of `width` columns and room for up to `height_capacity` rows. */
@@ -103,6 +106,25 @@ int32_t yalps_tableau_pivot(yalps_tableau *t, int32_t row, int32_t col);
  * events on the context's stream.  *avg_us_out = average kernel duration. */
 int32_t yalps_tableau_bench_sweep(yalps_tableau *t, int32_t row, int32_t col, int32_t launches,
                                   float *avg_us_out);
+
+/* ---- row-sharded solve of ONE tableau across GPUs (BASELINE config 5) ------------
+ * One process per GPU.  Each rank uploads a local tableau = objective row + its contiguous block
+ * of rows, declares the partition with yalps_tableau_set_shard (bounds[r]..bounds[r+1] = global
+ * rows of rank r, bounds[0] = 1, bounds[nranks] = global height; pos/var are the GLOBAL
+ * permutations, width + global height entries), then runs per pivot:
+ *     yalps_shard_select(t, send)            -- this rank's candidates + candidate rows
+ *     all-gather of yalps_shard_slot_doubles() doubles per rank   (caller: RCCL / torch.distributed)
+ *     yalps_shard_apply(t, gathered)         -- every rank picks the same winner and eliminates
+ * All calls only enqueue work on the context's stream; yalps_shard_poll synchronises and returns
+ * the replicated status (-1 = still running).  checkCycles is not available in this mode. */
+int32_t yalps_tableau_set_shard(yalps_tableau *t, int32_t rank, int32_t nranks, const int32_t *bounds,
+                                int32_t global_height, const int32_t *positionOfVariable,
+                                const int32_t *variableAtPosition);
+int64_t yalps_shard_slot_doubles(const yalps_tableau *t);
+int32_t yalps_shard_begin(yalps_tableau *t, double precision, double maxPivots);
+int32_t yalps_shard_select(yalps_tableau *t, double *send_dev);
+int32_t yalps_shard_apply(yalps_tableau *t, const double *gathered_dev);
+int32_t yalps_shard_poll(yalps_tableau *t, int32_t *status_out, double *result_out, int64_t *pivots_out);
 
 /* ---- synthetic input of the headline benchmark ---------------------------------------------
  * dense-LP(M,N,seed): fills a (M+1) x (N+1) row-major tableau with the

@@ -1,0 +1,52 @@
+"""Worker of the multi-process row-sharded tests: one rank of a gloo (or nccl) group.
+usage: python -m tests._shard_worker <numpy|hip> <M> <N> <seed> <out.npz>   (RANK/WORLD_SIZE/MASTER_* in env)"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    kind, M, N, seed, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests import _oracle
+    from yalps_amd import sharded
+    w, h = N + 1, M + 1
+    m = _oracle.load().dense_lp(M, N, seed)
+    if seed % 2:  # make some right-hand sides negative so that phase 1 runs too
+        m.reshape(h, w)[1::3, 0] *= -0.05
+    bounds = sharded.partition(h, world)
+    ident = np.arange(w + h, dtype=np.int32)
+    local = sharded.local_rows(m, w, h, bounds, rank)
+    if kind == "numpy":
+        from tests._shard_numpy import NumpyShardOps
+        ops = NumpyShardOps(local, w, bounds, rank, h, ident, ident.copy())
+    else:
+        ops = sharded.HipShardOps(local, w, bounds, rank, h, ident, ident.copy(), device=0)
+    comm = sharded.TorchComm()
+    status, result, pivots = sharded.sharded_simplex(ops, comm, max_pivots=float("inf"), check_every=8)
+    lm, pos, var = ops.download()
+    # assemble the global tableau on rank 0
+    parts = [None] * world
+    dist.all_gather_object(parts, (lm, bounds[rank], bounds[rank + 1]))
+    if rank == 0:
+        full = np.zeros((h, w))
+        for r, (pm, lo, hi) in enumerate(parts):
+            pm = pm.reshape(-1, w)
+            if r == 0:
+                full[0] = pm[0]
+            full[lo:hi] = pm[1:]
+        np.savez(out, matrix=full.reshape(-1), pos=pos, var=var, status=status, result=result, pivots=pivots)
+    ops.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

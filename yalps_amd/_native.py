@@ -20,7 +20,8 @@ SYMBOLS = (
     "yalps_ctx_destroy", "yalps_tableau_create", "yalps_tableau_destroy", "yalps_tableau_upload",
     "yalps_tableau_download", "yalps_tableau_download_rhs", "yalps_tableau_copy", "yalps_tableau_height",
     "yalps_tableau_solve", "yalps_tableau_pivot", "yalps_tableau_bench_sweep", "yalps_dense_lp_f64",
-    "yalps_round_to_precision",
+    "yalps_round_to_precision", "yalps_ctx_create_on_stream", "yalps_tableau_set_shard", "yalps_shard_slot_doubles",
+    "yalps_shard_begin", "yalps_shard_select", "yalps_shard_apply", "yalps_shard_poll",
 )
 
 
@@ -48,6 +49,20 @@ def lib():
                                            C.c_int32, f64p, C.POINTER(C.c_int64)]
         L.yalps_ctx_create.restype = C.c_int32
         L.yalps_ctx_create.argtypes = [C.c_int32, C.POINTER(vp)]
+        L.yalps_ctx_create_on_stream.restype = C.c_int32
+        L.yalps_ctx_create_on_stream.argtypes = [C.c_int32, vp, C.POINTER(vp)]
+        L.yalps_tableau_set_shard.restype = C.c_int32
+        L.yalps_tableau_set_shard.argtypes = [vp, C.c_int32, C.c_int32, vp, C.c_int32, vp, vp]
+        L.yalps_shard_slot_doubles.restype = C.c_int64
+        L.yalps_shard_slot_doubles.argtypes = [vp]
+        L.yalps_shard_begin.restype = C.c_int32
+        L.yalps_shard_begin.argtypes = [vp, C.c_double, C.c_double]
+        L.yalps_shard_select.restype = C.c_int32
+        L.yalps_shard_select.argtypes = [vp, vp]
+        L.yalps_shard_apply.restype = C.c_int32
+        L.yalps_shard_apply.argtypes = [vp, vp]
+        L.yalps_shard_poll.restype = C.c_int32
+        L.yalps_shard_poll.argtypes = [vp, C.POINTER(C.c_int32), f64p, C.POINTER(C.c_int64)]
         L.yalps_ctx_destroy.restype = None
         L.yalps_ctx_destroy.argtypes = [vp]
         L.yalps_tableau_create.restype = C.c_int32
@@ -105,9 +120,14 @@ def simplex_host(matrix, width, height, pos, var, precision=1e-8, max_pivots=819
 
 
 class Context:
-    def __init__(self, device=0):
+    def __init__(self, device=0, stream=None):
+        """stream: an existing HIP stream handle (int) to enqueue on, e.g.
+        torch.cuda.current_stream().cuda_stream; None = a private stream."""
         self.handle = C.c_void_p()
-        check(lib().yalps_ctx_create(device, C.byref(self.handle)))
+        if stream is None:
+            check(lib().yalps_ctx_create(device, C.byref(self.handle)))
+        else:
+            check(lib().yalps_ctx_create_on_stream(device, C.c_void_p(stream), C.byref(self.handle)))
 
     def close(self):
         if self.handle:
@@ -132,11 +152,12 @@ class DeviceTableau:
         check(lib().yalps_tableau_upload(self.handle, _ptr(matrix, np.float64), height, _ptr(pos, np.int32),
                                          _ptr(var, np.int32)))
 
-    def download(self, matrix=True, perms=True):
+    def download(self, matrix=True, perms=True, perm_len=None):
         h, w = self.height, self.width
+        n = perm_len if perm_len is not None else w + h
         m = np.empty(h * w, np.float64) if matrix else None
-        pos = np.empty(w + h, np.int32) if perms else None
-        var = np.empty(w + h, np.int32) if perms else None
+        pos = np.empty(n, np.int32) if perms else None
+        var = np.empty(n, np.int32) if perms else None
         check(lib().yalps_tableau_download(self.handle, _ptr(m, np.float64), _ptr(pos, np.int32), _ptr(var, np.int32)))
         return m, pos, var
 
@@ -162,6 +183,30 @@ class DeviceTableau:
         us = C.c_float()
         check(lib().yalps_tableau_bench_sweep(self.handle, row, col, launches, C.byref(us)))
         return us.value
+
+    # ---- row-sharded solve steps (yalps_amd/sharded.py drives them) ----
+    def set_shard(self, rank, nranks, bounds, global_height, pos, var):
+        b = np.ascontiguousarray(bounds, np.int32)
+        assert b.size == nranks + 1 and pos.size == self.width + global_height
+        check(lib().yalps_tableau_set_shard(self.handle, rank, nranks, b.ctypes.data, global_height,
+                                            _ptr(pos, np.int32), _ptr(var, np.int32)))
+
+    def shard_slot_doubles(self):
+        return int(lib().yalps_shard_slot_doubles(self.handle))
+
+    def shard_begin(self, precision, max_pivots):
+        check(lib().yalps_shard_begin(self.handle, precision, float(max_pivots)))
+
+    def shard_select(self, send_ptr):
+        check(lib().yalps_shard_select(self.handle, C.c_void_p(send_ptr)))
+
+    def shard_apply(self, gathered_ptr):
+        check(lib().yalps_shard_apply(self.handle, C.c_void_p(gathered_ptr)))
+
+    def shard_poll(self):
+        st, res, npiv = C.c_int32(), C.c_double(), C.c_int64()
+        check(lib().yalps_shard_poll(self.handle, C.byref(st), C.byref(res), C.byref(npiv)))
+        return st.value, res.value, npiv.value
 
     def close(self):
         if self.handle:

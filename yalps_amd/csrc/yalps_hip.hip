@@ -49,7 +49,9 @@
 namespace {
 
 constexpr int RUNNING = -1;
-constexpr int MODE_FUSED = 0, MODE_DECIDE = 1, MODE_APPLY = 2;
+constexpr int MODE_FUSED = 0, MODE_DECIDE = 1, MODE_APPLY = 2, MODE_SHARD = 3;
+constexpr int SHARD_HDR = 8;  // doubles in front of the two candidate rows of a gather slot
+constexpr int MAX_SHARDS = 8; // one node of MI355X
 constexpr int LAUNCHES_PER_GRAPH = 64; // even: state parity returns to 0 after a replay
 constexpr int MAX_BLOCKS = 1024;       // partial arrays / reduction width
 
@@ -103,6 +105,11 @@ struct Desc {
     Part *part_rhs[2];
     int32_t w, n, pitch, hcap; // n = w - 1 variable columns
     int32_t nb;                // workgroups of an APPLY/FUSED launch = row stride = number of partials
+    // row sharding over GPUs: this rank holds the objective row (local row 0,
+    // replicated) + global rows [bounds[rank], bounds[rank+1]) as local rows 1..; a local row
+    // r >= 1 is global row r + row_base.  Unsharded: nshards = 1, row_base = 0.
+    int32_t nshards, shard_rank, row_base;
+    int32_t bounds[MAX_SHARDS + 1];
 };
 
 // ------------------------------------------------------------------------------------------
@@ -259,7 +266,7 @@ __device__ __forceinline__ double2 with_elem(double2 v, int e, double x) {
 // draining it; vmcnt retires in issue order, hence the issue order below is deliberate.
 // ------------------------------------------------------------------------------------------
 template <int T, int J, int R, int D>
-__global__ __launch_bounds__(T) void pivot_kernel(Desc d, int parity, int mode, int force) {
+__global__ __launch_bounds__(T) void pivot_kernel(Desc d, int parity, int mode, int force, const double *gather) {
     __shared__ double sk[2][16];
     __shared__ int si[2][16];
     __shared__ double sh_la[2][R]; // next entering column's entries of my rows (ping-pong per batch)
@@ -344,12 +351,29 @@ __global__ __launch_bounds__(T) void pivot_kernel(Desc d, int parity, int mode, 
     }
 
     // (1) control loads first (oldest in the queue): partials of the previous launch, objective row
+    // (SHARD mode: the all-gathered per-rank candidates instead -- slot layout at shard_select_kernel)
+    const int gstride = SHARD_HDR + 2 * pitch;
+    const int ncand = mode == MODE_SHARD ? d.nshards : NB;
     Part p_rhs, p_ratio;
-    {
+    if (mode == MODE_SHARD) {
+        const double *slot_ = gather + (size_t)(tid < ncand ? tid : 0) * gstride;
+        p_ratio.key = slot_[0];
+        p_ratio.idx = (int)slot_[1];
+        p_rhs.key = slot_[2];
+        p_rhs.idx = (int)slot_[3];
+    } else {
         const int pi = tid < NB ? tid : 0;
         p_rhs = d.part_rhs[pbuf][pi];
         p_ratio = d.part_ratio[pbuf][pi];
     }
+    // where a (global) row's raw data and RHS entry come from: my tableau, or its owner's gather slot
+    auto owner_slot = [&](int grow) {
+        int g = 0;
+#pragma unroll
+        for (int k = 1; k < MAX_SHARDS; k++)
+            if (k < d.nshards && grow >= d.bounds[k]) g = k;
+        return gather + (size_t)g * gstride;
+    };
     double2 o[J]; // objective row slice (reduced costs)
 #pragma unroll
     for (int j = 0; j < J; j++) o[j] = *reinterpret_cast<const double2 *>(matA + cofs[j]);
@@ -385,7 +409,7 @@ __global__ __launch_bounds__(T) void pivot_kernel(Desc d, int parity, int mode, 
             if (phase == 1) {
                 // leaving row: most negative RHS, strict <, first wins (:111-119)
                 KI c = {INFINITY, INT_MAX};
-                if (tid < NB) {
+                if (tid < ncand) {
                     c.k = p_rhs.key;
                     c.i = p_rhs.idx;
                 }
@@ -399,7 +423,8 @@ __global__ __launch_bounds__(T) void pivot_kernel(Desc d, int parity, int mode, 
                 }
                 row = c.i;
                 // entering column: max -M[0,c]/M[row,c] over M[row,c] < -precision (:123-134)
-                const double *mrow = matA + (size_t)row * pitch;
+                const double *mrow = mode == MODE_SHARD ? owner_slot(row) + SHARD_HDR + pitch
+                                                       : matA + (size_t)row * pitch;
                 KI e = {INFINITY, INT_MAX};
 #pragma unroll
                 for (int j = 0; j < J; j++) {
@@ -436,7 +461,7 @@ __global__ __launch_bounds__(T) void pivot_kernel(Desc d, int parity, int mode, 
                 // leaving row: min-ratio test with the early break (:83-95); the partials carry
                 // key = -inf for "ratio <= precision" rows so the lowest such index wins
                 KI c = {INFINITY, INT_MAX};
-                if (tid < NB) {
+                if (tid < ncand) {
                     c.k = p_ratio.key;
                     c.i = p_ratio.idx;
                 }
@@ -505,13 +530,20 @@ __global__ __launch_bounds__(T) void pivot_kernel(Desc d, int parity, int mode, 
     const int col_tid = have_pivot ? ucol % T : -1, col_j = have_pivot ? ucol / T : -1;
     const int colx = have_pivot ? col - 1 : 0; // in-bounds even without a pivot
     // (3) pivot row, quotient, objective row's pivot-column entry
+    // (SHARD: the pivot row travels in its owner's gather slot -- the ratio candidate's row in
+    // phase 2, the most-negative-RHS candidate's row in phase 1; `row` is a GLOBAL index and
+    // `lrow` its local index here, -1 if another rank owns it)
+    const double *gslot = mode == MODE_SHARD ? owner_slot(row) : nullptr;
+    const double *mrow = mode == MODE_SHARD ? gslot + SHARD_HDR + (phase == 1 ? pitch : 0) : matA + (size_t)row * pitch;
+    const int lrow = !have_pivot ? -1
+                     : mode != MODE_SHARD ? row
+                     : (row >= d.bounds[d.shard_rank] && row < d.bounds[d.shard_rank + 1]) ? row - d.row_base : -1;
     if (!pv_loaded) {
-        const double *mrow = matA + (size_t)row * pitch;
 #pragma unroll
         for (int j = 0; j < J; j++) pv[j] = *reinterpret_cast<const double2 *>(mrow + cofs[j]);
     }
-    const double q_ld = matA[(size_t)row * pitch + colx], coef0_ld = matA[colx];
-    const double rhs_row = rhsA[row];
+    const double q_ld = mrow[colx], coef0_ld = matA[colx];
+    const double rhs_row = mode == MODE_SHARD ? gslot[phase == 1 ? 5 : 4] : rhsA[row];
     const double q = have_pivot ? q_ld : 1.0, coef0 = have_pivot ? coef0_ld : 0.0;
 
     unsigned nzmask = 0; // bit (2j+k): pivot-row entry is in nonZeroColumns (:18-23)
@@ -564,7 +596,7 @@ __global__ __launch_bounds__(T) void pivot_kernel(Desc d, int parity, int mode, 
                 if (tid == g) my_coef = coef[g];
             const bool nz_rhs = fabs(rhs_row) > 1e-16;
             const double pn_rhs = nz_rhs ? rhs_row / q : 0.0;
-            if (my_r == row) {
+            if (my_r == lrow) {
                 my_rhs = pn_rhs;
             } else if (fabs(my_coef) > 1e-16) {
                 if (nz_rhs) {
@@ -587,8 +619,8 @@ __global__ __launch_bounds__(T) void pivot_kernel(Desc d, int parity, int mode, 
             const int r = b + NB * (i0 + g);
             const bool live = r < h;
             const double c = coef[g];
-            const bool act = have_pivot && live && r != row && fabs(c) > 1e-16;
-            if (have_pivot && live && r == row) {
+            const bool act = have_pivot && live && r != lrow && fabs(c) > 1e-16;
+            if (have_pivot && live && r == lrow) {
 #pragma unroll
                 for (int j = 0; j < J; j++) {
                     x[g][j] = pv[j];
@@ -674,9 +706,10 @@ __global__ __launch_bounds__(T) void pivot_kernel(Desc d, int parity, int mode, 
         __syncthreads(); // sh_la of this batch visible to lanes 0..R-1
         // candidates of my row for the next launch's scans
         if (my_live && my_r >= 1) {
-            if (my_rhs < -precision && ki_better(my_rhs, my_r, cand_rhs.k, cand_rhs.i)) {
+            const int my_gr = my_r + d.row_base; // global row index
+            if (my_rhs < -precision && ki_better(my_rhs, my_gr, cand_rhs.k, cand_rhs.i)) {
                 cand_rhs.k = my_rhs;
-                cand_rhs.i = my_r;
+                cand_rhs.i = my_gr;
             }
             if (la > 0) {
                 const double value = (my_val_set && la == col) ? my_val : sh_la[(i0 / R) & 1][tid];
@@ -684,9 +717,9 @@ __global__ __launch_bounds__(T) void pivot_kernel(Desc d, int parity, int mode, 
                     const double ratio = my_rhs / value;
                     if (ratio < INFINITY) {
                         const double key = (ratio <= precision) ? -INFINITY : ratio;
-                        if (ki_better(key, my_r, cand_ratio.k, cand_ratio.i)) {
+                        if (ki_better(key, my_gr, cand_ratio.k, cand_ratio.i)) {
                             cand_ratio.k = key;
-                            cand_ratio.i = my_r;
+                            cand_ratio.i = my_gr;
                         }
                     }
                 }
@@ -709,10 +742,53 @@ __global__ __launch_bounds__(T) void pivot_kernel(Desc d, int parity, int mode, 
     }
     apply_swap();
     if (b == 0 && tid == 0 && !(force & 1)) {
-        const bool counted = have_pivot && mode == MODE_FUSED; // DECIDE already counted an APPLY's pivot
+        const bool counted = have_pivot && mode != MODE_APPLY; // DECIDE already counted an APPLY's pivot
         write_state(RUNNING, phase, 0, la, pbuf ^ 1, mbuf ^ 1, 0, 0, 0, 0, have_pivot ? 1 : 0, row, col,
-                    (mode == MODE_FUSED && phase_switched) ? 0 : hist_len_in, counted ? iter + 1.0 : iter, NAN,
+                    (mode != MODE_APPLY && phase_switched) ? 0 : hist_len_in, counted ? iter + 1.0 : iter, NAN,
                     counted ? pivots_in + 1 : pivots_in);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// shard_select_kernel: one workgroup per rank, between two pivots of a row-sharded solve.
+// Reduces this rank's per-workgroup partials to its two candidates and packs them, WITH the
+// candidate rows, into the rank's slot of the all-gather (so the selection and the pivot-row
+// broadcast of SURVEY.md 8e are a single collective of nshards x (8 + 2*pitch) doubles):
+//   [0] ratio key  [1] ratio row (global)  [2] rhs key  [3] rhs row (global)
+//   [4] RHS entry of the ratio row  [5] RHS entry of the rhs row  [6..7] pad
+//   [8 .. 8+pitch) raw ratio-candidate row   [8+pitch .. 8+2*pitch) raw rhs-candidate row
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void shard_select_kernel(Desc d, int parity, double *send) {
+    __shared__ double sk[2][16];
+    __shared__ int si[2][16];
+    const YState *S = d.st + parity;
+    const int tid = threadIdx.x, NB = d.nb, pitch = d.pitch;
+    const bool idle = S->status != RUNNING || S->pause || S->bootstrap;
+    KI cr = {INFINITY, INT_MAX}, cn = {INFINITY, INT_MAX};
+    if (!idle && tid < NB) {
+        const Part a = d.part_ratio[S->pbuf][tid], c = d.part_rhs[S->pbuf][tid];
+        cr.k = a.key;
+        cr.i = a.idx;
+        cn.k = c.key;
+        cn.i = c.idx;
+    }
+    cr = block_argmin<1024>(cr, sk, si, 0);
+    cn = block_argmin<1024>(cn, sk, si, 1);
+    const double *mat = d.mat[S->mbuf], *rhs = d.rhs[S->mbuf];
+    const int lr = cr.i == INT_MAX ? 0 : cr.i - d.row_base, ln = cn.i == INT_MAX ? 0 : cn.i - d.row_base;
+    if (tid == 0) {
+        send[0] = cr.k;
+        send[1] = (double)cr.i;
+        send[2] = cn.k;
+        send[3] = (double)cn.i;
+        send[4] = rhs[lr];
+        send[5] = rhs[ln];
+        send[6] = 0.0;
+        send[7] = 0.0;
+    }
+    for (int c = tid; c < pitch; c += 1024) {
+        send[SHARD_HDR + c] = mat[(size_t)lr * pitch + c];
+        send[SHARD_HDR + pitch + c] = mat[(size_t)ln * pitch + c];
     }
 }
 
@@ -733,7 +809,7 @@ __global__ void flush_swap_kernel(Desc d, int parity) {
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-using KernelFn = void (*)(Desc, int, int, int);
+using KernelFn = void (*)(Desc, int, int, int, const double *);
 
 struct Variant {
     int T, J, R;
@@ -773,6 +849,7 @@ int env_int(const char *name, int dflt) {
 struct yalps_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    bool own_stream = true;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool eager = false;
     bool nt_stores = false;
@@ -784,6 +861,8 @@ struct yalps_tableau {
     Desc d{};
     int32_t height = 0;
     int cur = 0; // tableau buffer holding the current tableau
+    int shard_parity = 0;
+    int32_t perm_len = 0; // entries of pos / var (width + GLOBAL height)
     Variant var{};
     int nb = 1;
     hipGraph_t graph[2] = {nullptr, nullptr}; // [0] fused, [1] decide/apply (checkCycles)
@@ -798,7 +877,7 @@ namespace {
 
 void launch_one(yalps_tableau *t, int parity, int mode, int force) {
     const int grid = mode == MODE_DECIDE ? 1 : t->nb;
-    t->var.fn<<<dim3(grid), dim3(t->var.T), 0, t->ctx->stream>>>(t->d, parity, mode, force);
+    t->var.fn<<<dim3(grid), dim3(t->var.T), 0, t->ctx->stream>>>(t->d, parity, mode, force, nullptr);
 }
 
 int launch_batch(yalps_tableau *t, int which) {
@@ -917,7 +996,7 @@ void yalps_dense_lp_f64(int32_t M, int32_t N, double seed, double *matrix) {
     }
 }
 
-int32_t yalps_ctx_create(int32_t device, yalps_ctx **out) {
+static int32_t ctx_create(int32_t device, void *ext_stream, bool adopt, yalps_ctx **out) {
     if (!out) return fail(YALPS_E_ARG, "yalps_ctx_create: out is NULL");
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
@@ -930,7 +1009,12 @@ int32_t yalps_ctx_create(int32_t device, yalps_ctx **out) {
         return fail(YALPS_E_DEVICE, std::string("device is ") + prop.gcnArchName + ", this build targets gfx950 only");
     yalps_ctx *c = new yalps_ctx();
     c->device = device;
-    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    if (adopt) {
+        c->stream = static_cast<hipStream_t>(ext_stream); // e.g. torch's current stream (may be the null stream)
+        c->own_stream = false;
+    } else {
+        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    }
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
     c->eager = env_int("YALPS_HIP_EAGER", 0) != 0;
@@ -942,12 +1026,18 @@ int32_t yalps_ctx_create(int32_t device, yalps_ctx **out) {
     return 0;
 }
 
+int32_t yalps_ctx_create(int32_t device, yalps_ctx **out) { return ctx_create(device, nullptr, false, out); }
+
+int32_t yalps_ctx_create_on_stream(int32_t device, void *hip_stream, yalps_ctx **out) {
+    return ctx_create(device, hip_stream, true, out);
+}
+
 void yalps_ctx_destroy(yalps_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -982,6 +1072,11 @@ int32_t yalps_tableau_create(yalps_ctx *ctx, int32_t width, int32_t hcap, yalps_
     d.n = n;
     d.hcap = hcap;
     d.nb = t->nb;
+    d.nshards = 1;
+    d.shard_rank = 0;
+    d.row_base = 0;
+    for (int k = 0; k <= MAX_SHARDS; k++) d.bounds[k] = k == 0 ? 0 : INT_MAX;
+    t->perm_len = width + hcap;
     d.pitch = (n + 15) / 16 * 16; // 128-byte rows
     if (d.pitch < 16) d.pitch = 16;
     const size_t mat_bytes = sizeof(double) * (size_t)d.pitch * hcap;
@@ -1042,7 +1137,9 @@ int32_t yalps_tableau_upload(yalps_tableau *t, const double *matrix, int32_t hei
     if (d.n > 0)
         HIP_TRY(hipMemcpy2DAsync(d.mat[0], sizeof(double) * d.pitch, matrix + 1, sizeof(double) * d.w,
                                  sizeof(double) * d.n, height, hipMemcpyHostToDevice, s));
+    if (t->d.nshards > 1) return fail(YALPS_E_ARG, "yalps_tableau_upload: tableau is sharded; create a new one");
     const size_t nperm = sizeof(int32_t) * (size_t)(d.w + height);
+    t->perm_len = d.w + height;
     HIP_TRY(hipMemcpyAsync(d.pos, pos, nperm, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d.var, var, nperm, hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -1062,7 +1159,7 @@ int32_t yalps_tableau_download(yalps_tableau *t, double *matrix, int32_t *pos, i
             HIP_TRY(hipMemcpy2DAsync(matrix + 1, sizeof(double) * d.w, d.mat[t->cur], sizeof(double) * d.pitch,
                                      sizeof(double) * d.n, t->height, hipMemcpyDeviceToHost, s));
     }
-    const size_t nperm = sizeof(int32_t) * (size_t)(d.w + t->height);
+    const size_t nperm = sizeof(int32_t) * (size_t)t->perm_len;
     if (pos) HIP_TRY(hipMemcpyAsync(pos, d.pos, nperm, hipMemcpyDeviceToHost, s));
     if (var) HIP_TRY(hipMemcpyAsync(var, d.var, nperm, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -1080,7 +1177,8 @@ int32_t yalps_tableau_download_rhs(yalps_tableau *t, double *col0) {
 
 int32_t yalps_tableau_copy(yalps_tableau *dst, const yalps_tableau *src) {
     if (!dst || !src) return fail(YALPS_E_ARG, "yalps_tableau_copy: NULL argument");
-    if (dst->d.w != src->d.w || dst->d.hcap < src->height || dst->ctx != src->ctx)
+    if (dst->d.w != src->d.w || dst->d.hcap < src->height || dst->ctx != src->ctx || src->d.nshards > 1 ||
+        dst->d.nshards > 1)
         return fail(YALPS_E_ARG, "yalps_tableau_copy: incompatible tableaux");
     HIP_TRY(hipSetDevice(dst->ctx->device));
     hipStream_t s = dst->ctx->stream;
@@ -1094,6 +1192,7 @@ int32_t yalps_tableau_copy(yalps_tableau *dst, const yalps_tableau *src) {
     HIP_TRY(hipMemcpyAsync(dst->d.var, src->d.var, nperm, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));
     dst->height = src->height;
+    dst->perm_len = src->perm_len;
     return 0;
 }
 
@@ -1206,6 +1305,85 @@ int32_t yalps_tableau_bench_sweep(yalps_tableau *t, int32_t row, int32_t col, in
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     if (avg_us_out) *avg_us_out = ms * 1000.f / (float)launches;
+    return 0;
+}
+
+// ---- row-sharded solve across GPUs (one process per GPU) ------------------------
+// The library provides the per-rank steps, enqueued on the context's stream; the caller owns the
+// collective between them (an all-gather of yalps_shard_slot_doubles() doubles per rank -- RCCL
+// through torch.distributed in yalps_amd/sharded.py).
+int32_t yalps_tableau_set_shard(yalps_tableau *t, int32_t rank, int32_t nranks, const int32_t *bounds,
+                                int32_t global_height, const int32_t *pos, const int32_t *var) {
+    if (!t || !bounds || !pos || !var || nranks < 1 || nranks > MAX_SHARDS || rank < 0 || rank >= nranks)
+        return fail(YALPS_E_ARG, "yalps_tableau_set_shard: bad argument");
+    if (t->height != 1 + bounds[rank + 1] - bounds[rank] || bounds[0] != 1 || bounds[nranks] != global_height)
+        return fail(YALPS_E_ARG, "yalps_tableau_set_shard: uploaded rows do not match bounds (objective row + own rows)");
+    HIP_TRY(hipSetDevice(t->ctx->device));
+    hipStream_t s = t->ctx->stream;
+    Desc &d = t->d;
+    d.nshards = nranks;
+    d.shard_rank = rank;
+    d.row_base = bounds[rank] - 1;
+    for (int k = 0; k <= MAX_SHARDS; k++) d.bounds[k] = k <= nranks ? bounds[k] : INT_MAX;
+    // the permutations are global (every rank replays the same basis swaps)
+    const size_t n = (size_t)d.w + (size_t)global_height;
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipFree(d.pos));
+    HIP_TRY(hipFree(d.var));
+    HIP_TRY(hipMalloc(&d.pos, sizeof(int32_t) * n));
+    HIP_TRY(hipMalloc(&d.var, sizeof(int32_t) * n));
+    HIP_TRY(hipMemcpyAsync(d.pos, pos, sizeof(int32_t) * n, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d.var, var, sizeof(int32_t) * n, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    t->perm_len = (int32_t)n;
+    // graphs captured for the unsharded tableau hold the old Desc
+    for (int k = 0; k < 2; k++) {
+        if (t->graph_exec[k]) (void)hipGraphExecDestroy(t->graph_exec[k]);
+        if (t->graph[k]) (void)hipGraphDestroy(t->graph[k]);
+        t->graph_exec[k] = nullptr;
+        t->graph[k] = nullptr;
+    }
+    return 0;
+}
+
+int64_t yalps_shard_slot_doubles(const yalps_tableau *t) { return t ? SHARD_HDR + 2 * (int64_t)t->d.pitch : 0; }
+
+int32_t yalps_shard_begin(yalps_tableau *t, double precision, double maxPivots) {
+    if (!t || t->height < 1) return fail(YALPS_E_ARG, "yalps_shard_begin: no tableau uploaded");
+    HIP_TRY(hipSetDevice(t->ctx->device));
+    int rc = init_state(t, precision, maxPivots, 0);
+    if (rc) return rc;
+    launch_one(t, 0, MODE_FUSED, 0); // bootstrap scan: emits this rank's first partials
+    HIP_TRY(hipGetLastError());
+    t->shard_parity = 1;
+    return 0;
+}
+
+int32_t yalps_shard_select(yalps_tableau *t, double *send_dev) {
+    if (!t || !send_dev) return fail(YALPS_E_ARG, "yalps_shard_select: bad argument");
+    shard_select_kernel<<<dim3(1), dim3(1024), 0, t->ctx->stream>>>(t->d, t->shard_parity, send_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int32_t yalps_shard_apply(yalps_tableau *t, const double *gathered_dev) {
+    if (!t || !gathered_dev) return fail(YALPS_E_ARG, "yalps_shard_apply: bad argument");
+    t->var.fn<<<dim3(t->nb), dim3(t->var.T), 0, t->ctx->stream>>>(t->d, t->shard_parity, MODE_SHARD, 0, gathered_dev);
+    HIP_TRY(hipGetLastError());
+    t->shard_parity ^= 1;
+    return 0;
+}
+
+int32_t yalps_shard_poll(yalps_tableau *t, int32_t *status_out, double *result_out, int64_t *pivots_out) {
+    if (!t) return fail(YALPS_E_ARG, "yalps_shard_poll: bad argument");
+    HIP_TRY(hipSetDevice(t->ctx->device));
+    HIP_TRY(hipStreamSynchronize(t->ctx->stream));
+    YState now;
+    HIP_TRY(hipMemcpy(&now, t->d.st + t->shard_parity, sizeof(YState), hipMemcpyDeviceToHost));
+    if (now.status != RUNNING) t->cur = now.mbuf;
+    if (status_out) *status_out = now.status;
+    if (result_out) *result_out = now.result;
+    if (pivots_out) *pivots_out = now.pivots;
     return 0;
 }
 
