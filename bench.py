@@ -5,11 +5,15 @@ A "step" = one complete two-phase simplex solve of dense-LP(2048,2048,seed) (BAS
 tableau 2049 x 2049 fp64, 3923 pivots for seed 42) by the HIP path, starting from a pristine
 copy of the tableau that is already resident in HBM.  value = pivots executed / wall time.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--size 2048]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--size 2048] [--workload replicas|sharded]
   N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
          one process per GPU; every rank solves its own LP (seed 42 + rank) -- independent
          sub-problems shard with no data-path collective (weak scaling); torch.distributed
          (RCCL) only provides the barriers and the max-over-ranks reduction of the time.
+
+  --workload sharded (optional, BASELINE config 5): ONE dense-LP(size,size,42) row-sharded over the
+         N ranks (yalps_amd/sharded.py: one RCCL all-gather of candidates + candidate rows per pivot);
+         a step = --pivots-per-step pivots of that solve; strong scaling.
 
 Extra objects on the JSON line (N == 1 / rank 0 only):
   roofline      the dominant (only) kernel, pivot_kernel: ONE launch = one complete pivot
@@ -69,6 +73,8 @@ def main():
     ap.add_argument("--cpu-pivots", type=float, default=float("inf"),
                     help="oracle sample: first N pivots of the same LP (default: the whole solve, ~7 s; 0 = skip)")
     ap.add_argument("--sweep-launches", type=int, default=400)
+    ap.add_argument("--workload", choices=("replicas", "sharded"), default="replicas")
+    ap.add_argument("--pivots-per-step", type=int, default=256, help="sharded workload: pivots per step")
     args = ap.parse_args()
 
     import torch
@@ -85,6 +91,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    if args.workload == "sharded":
+        return bench_sharded(args, torch, dist, rank, local_rank, world)
 
     from yalps_amd import _native
     M = N = args.size
@@ -163,6 +172,54 @@ def main():
         dist.destroy_process_group()
     if out is not None:
         print(json.dumps(out))
+
+
+def bench_sharded(args, torch, dist, rank, local_rank, world):
+    """ONE tableau row-sharded over the ranks; every rank generates the LP and keeps its block."""
+    from yalps_amd import _native, sharded
+    M = N = args.size
+    w, h = N + 1, M + 1
+    m = _native.dense_lp(M, N, 42)
+    bounds = sharded.partition(h, world)
+    ident = np.arange(w + h, dtype=np.int32)
+    local = sharded.local_rows(m, w, h, bounds, rank)
+    del m
+    comm = sharded.TorchComm()
+
+    def run(pivots):
+        ops = sharded.HipShardOps(local, w, bounds, rank, h, ident, ident.copy(), device=local_rank)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        status, result, npiv = sharded.sharded_simplex(ops, comm, max_pivots=float(pivots), check_every=64)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        ops.close()
+        return dt, npiv, status
+
+    run(args.pivots_per_step * max(args.warmup, 1))
+    dt, npiv, status = run(args.pivots_per_step * args.steps)
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = t.item()
+    if rank == 0:
+        bpp = algorithmic_bytes_per_pivot(h, w)
+        print(json.dumps({
+            "metric": "fp64 pivots/sec on dense m x n tableau", "value": npiv / dt, "unit": "pivots/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "ONE dense-LP(%d,%d,seed=42), tableau %dx%d fp64, rows sharded over %d GPU(s), "
+                                   "one all-gather of candidates+rows per pivot; %d pivots per step (status %s)"
+                                   % (M, N, h, w, world, args.pivots_per_step, status)},
+            "roofline": {"bound": "hbm", "achieved": bpp * npiv / dt / 1e9 / world, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": bpp * npiv / dt / 1e9 / world / HBM_PEAK_GBPS, "traffic": None,
+                         "note": "per GPU: algorithmic bytes of the whole tableau per pivot / n_gpus / time"}}))
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
