@@ -47,6 +47,17 @@ def algorithmic_bytes_per_pivot(h, w):
     return 16 * (h - 1) * w + 16 * w + 8 * (h - 1) + 8 * (w - 1) + 16 * (h - 1)
 
 
+def measured_traffic(size):
+    """HBM bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, corrected as
+    MI355X_MICROARCH.md prescribes), collected in separate rocprofv3 --pmc passes of this same
+    workload and committed under profiles/ -- bench.py cannot run the profiler on itself."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if size != 2048 or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)["traffic_bytes_per_launch"]
+
+
 def cpu_baseline(M, N, seed, budget_pivots):
     """Oracle (kind "port") on a bounded sample: the first `budget_pivots` pivots of the same LP
     (all of them by default: 3923 pivots of the 2049x2049 tableau take ~7-10 s on one core)."""
@@ -155,7 +166,8 @@ def main():
             us = 1e3 * gpu_ms / pivots
             ach = bpp / (us * 1e-6) / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK_GBPS, "traffic": None, "kernel": "pivot_kernel<1024,1,9,9>",
+                               "frac": ach / HBM_PEAK_GBPS, "traffic": measured_traffic(args.size),
+                               "kernel": "pivot_kernel<1024,1,9,9>",
                                "avg_us": us, "bytes_per_launch": bpp,
                                "note": "one launch = one pivot; HIP events over the timed pivot loops / pivots"}
             work.copy_from(pristine)
