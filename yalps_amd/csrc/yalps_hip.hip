@@ -110,6 +110,12 @@ struct Desc {
     // r >= 1 is global row r + row_base.  Unsharded: nshards = 1, row_base = 0.
     int32_t nshards, shard_rank, row_base;
     int32_t bounds[MAX_SHARDS + 1];
+    // resident (on-chip) solver: per-workgroup candidate hand-off buffers, ping-pong by epoch parity
+    double *rc_rows[2];             // [nb][pitch] candidate row of each workgroup
+    double *rc_key[2];              // [nb] RHS entry of each workgroup's candidate row
+    unsigned long long *rc_flag[2]; // [nb][2] {candidate key bits, (epoch << 32) | global row index}
+    int32_t *rc_err;                // set when a workgroup gives up waiting (never expected)
+    int32_t perm_len;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -792,6 +798,422 @@ __global__ __launch_bounds__(1024) void shard_select_kernel(Desc d, int parity, 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// resident_kernel: the whole pivot loop in ONE launch, tableau resident in the register files.
+//
+// Applies when the tableau fits on chip (2049 x 2049 fp64 = 33.6 MB against 128 MB of VGPRs): one
+// workgroup per CU keeps its rows (b, b+NB, ...) in registers for the whole solve; every workgroup
+// also keeps a replica of the objective row.  Per pivot the ONLY traffic is one exchange through
+// L2: every workgroup publishes its candidate (min-ratio row in phase 2, most-negative-RHS row in
+// phase 1) together with that row's data, all workgroups read the NB (key, row) pairs, take the
+// same arg-min and fetch the winner's row.  Nothing is streamed from or to HBM inside the loop.
+//
+// Hand-off = Guideline 16 R1 of the CDNA guide, table row 1: payload stored write-through (agent-
+// scope relaxed atomic stores = sc1), every storing wave drains (s_waitcnt vmcnt(0)), workgroup
+// barrier, ONE lane stores the flag {epoch, row}; consumers poll that one word per producer with
+// sc1 loads, join a workgroup barrier, then read the payload with sc1 loads only.  Buffers are
+// ping-ponged by epoch parity: a workgroup cannot get two epochs ahead of another one because it
+// needs that workgroup's flag of the epoch in between.  Results do not depend on placement or
+// timing: every decision is a deterministic function of bytes that are identical for all readers.
+// Every spin is bounded; a give-up sets rc_err and the host re-runs the chunk with the streaming
+// kernel from the untouched input buffer.
+//
+// The kernel runs at most `chunk` pivots per launch (bounded run time; the host relaunches while
+// the status is RUNNING) and writes the tableau to the OTHER buffer on exit.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void st_sc1(double *p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_sc1(const double *p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p),
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+template <int T, int J, int R>
+__global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chunk) {
+    __shared__ double sk[2][16];
+    __shared__ int si[2][16];
+    __shared__ double sh_val[R + 2]; // per-row broadcast: pivot-column entry / entering-column entry
+    __shared__ double sh_nq[R + 2];  // -coef/quotient per row (:36), for the objective row, 1/quotient (:25)
+    __shared__ double sh_ck;         // my candidate for the next exchange: key, row, local slot
+    __shared__ int sh_ci, sh_cg, sh_fail;
+    extern __shared__ int sh_perm[]; // workgroup 0: var[perm_len] then pos[perm_len]
+
+    const int tid = threadIdx.x, NB = d.nb, b = blockIdx.x;
+    const YState *Sin = d.st + parity;
+    YState *Sout = d.st + (parity ^ 1);
+    const YConst *C = d.cst;
+    if (Sin->status != RUNNING) {
+        if (b == 0 && tid == 0) state_copy(Sout, Sin);
+        return;
+    }
+    const int h = C->height, n = d.n, pitch = d.pitch, w = d.w;
+    const double precision = C->precision, max_pivots = C->max_pivots;
+    const int mbuf = Sin->mbuf;
+    const double *matA = d.mat[mbuf];
+    const double *rhsA = d.rhs[mbuf];
+    int phase = Sin->phase;
+    double iter = Sin->iter;
+    int64_t pivots = Sin->pivots;
+    int slot = 0;
+
+    int cofs[J];
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+        const int c0 = 2 * (tid + j * T);
+        cofs[j] = c0 < pitch ? c0 : 0;
+    }
+    // ---- load my rows, the objective replica, my rows' RHS (lane g), the basis (workgroup 0) ----
+    double2 x[R][J], o[J];
+#pragma unroll
+    for (int j = 0; j < J; j++) o[j] = *reinterpret_cast<const double2 *>(matA + cofs[j]);
+#pragma unroll
+    for (int g = 0; g < R; g++) {
+        const int r = b + NB * g;
+        const double *mr = matA + (size_t)(r < h ? r : b) * pitch;
+#pragma unroll
+        for (int j = 0; j < J; j++) x[g][j] = *reinterpret_cast<const double2 *>(mr + cofs[j]);
+    }
+    const int my_r = b + NB * tid; // lane g = tid < R owns the scalar side of row g
+    const bool my_live = tid < R && my_r < h;
+    double my_rhs = rhsA[my_live ? my_r : 0];
+    if (b == 0) {
+        for (int i = tid; i < d.perm_len; i += T) {
+            sh_perm[i] = d.var[i];
+            sh_perm[d.perm_len + i] = d.pos[i];
+        }
+    }
+    if (tid == 0) sh_fail = 0;
+    __syncthreads();
+
+    // my candidates for the next exchange, from the rows as they are + entering column `la`
+    int la = 0;
+    auto scan = [&]() {
+        // Dantzig pricing (src/simplex.ts:71-79) on my replica of the objective row
+        KI best = {INFINITY, INT_MAX};
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            const int c0 = 2 * (tid + j * T);
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const double ov = elem(o[j], k);
+                if (c0 + k < n && ov > precision && ki_better(-ov, c0 + k + 1, best.k, best.i)) {
+                    best.k = -ov;
+                    best.i = c0 + k + 1;
+                }
+            }
+        }
+        best = block_argmin<T>(best, sk, si, slot);
+        slot ^= 1;
+        la = best.i == INT_MAX ? 0 : best.i;
+        const int ula = (la - 1) >> 1, ela = (la - 1) & 1;
+        if (la > 0 && tid == ula % T) {
+#pragma unroll
+            for (int g = 0; g < R; g++)
+#pragma unroll
+                for (int j = 0; j < J; j++)
+                    if (j == ula / T) sh_val[g] = elem(x[g][j], ela);
+        }
+        __syncthreads();
+    };
+    // lanes 0..R-1: candidate of my row of the given kind (1 = most negative RHS, 2 = min ratio),
+    // reduced over the workgroup and left in sh_ck / sh_ci / sh_cg for every lane
+    auto candidate = [&](int kind) {
+        KI c = {INFINITY, INT_MAX};
+        if (my_live && my_r >= 1) {
+            if (kind == 1) {
+                if (my_rhs < -precision) {
+                    c.k = my_rhs;
+                    c.i = my_r;
+                }
+            } else if (la > 0) {
+                const double value = sh_val[tid];
+                if (value > precision) {
+                    const double ratio = my_rhs / value;
+                    if (ratio < INFINITY) {
+                        c.k = (ratio <= precision) ? -INFINITY : ratio;
+                        c.i = my_r;
+                    }
+                }
+            }
+        }
+        if (tid < 64) {
+            c = wave_argmin(c);
+            if (tid == 0) {
+                sh_ck = c.k;
+                sh_ci = c.i;
+                sh_cg = c.i == INT_MAX ? 0 : c.i / NB;
+            }
+        }
+        __syncthreads();
+    };
+
+    scan();
+    unsigned epoch = 0;
+    int done = 0, term = RUNNING;
+    double term_result = NAN;
+    for (;;) {
+        if (done == chunk) break;
+        if (!(iter < max_pivots)) { // src/simplex.ts:69,109
+            term = YALPS_CYCLED;
+            break;
+        }
+        if (phase == 2 && la == 0) { // :80
+            term = YALPS_OPTIMAL;
+            break;
+        }
+        // ---------------- publish my candidate + its row, gather everyone's ----------------------
+        candidate(phase);
+        epoch++;
+        const int par = epoch & 1;
+        {
+            const int cg = sh_cg;
+            double2 v[J];
+#pragma unroll
+            for (int j = 0; j < J; j++) v[j] = x[0][j];
+#pragma unroll
+            for (int g = 1; g < R; g++)
+                if (g == cg) {
+#pragma unroll
+                    for (int j = 0; j < J; j++) v[j] = x[g][j];
+                }
+            double *dst = d.rc_rows[par] + (size_t)b * pitch;
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                const int c0 = 2 * (tid + j * T);
+                if (c0 < pitch) {
+                    st_sc1(dst + c0, v[j].x);
+                    st_sc1(dst + c0 + 1, v[j].y);
+                }
+            }
+            if (tid == cg) st_sc1(d.rc_key[par] + b, my_rhs); // the candidate row's RHS entry (lane cg)
+            if (tid == 0) // the key travels next to the flag: one 16-byte record per workgroup
+                __hip_atomic_store(d.rc_flag[par] + 2 * b, (unsigned long long)__double_as_longlong(sh_ck),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains ...
+            __syncthreads();                                  // ... before ONE lane raises the flag
+            if (tid == 0)
+                __hip_atomic_store(d.rc_flag[par] + 2 * b + 1, ((unsigned long long)epoch << 32) | (unsigned)sh_ci,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        KI c = {INFINITY, INT_MAX};
+        if (tid < NB) {
+            // The key word was stored and drained before the flag word of the same 16-byte record,
+            // and is read AFTER the poll matched (program order of two sc1 loads of one lane).
+            unsigned long long f = 0;
+            unsigned spins = 0;
+            for (;;) {
+                f = __hip_atomic_load(d.rc_flag[par] + 2 * tid + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(f >> 32) == epoch) break;
+                if (++spins > (1u << 22) || __hip_atomic_load(d.rc_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    sh_fail = 1;
+                    __hip_atomic_store(d.rc_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            c.i = (int)(unsigned)f;
+            c.k = __longlong_as_double((long long)__hip_atomic_load(d.rc_flag[par] + 2 * tid, __ATOMIC_RELAXED,
+                                                                    __HIP_MEMORY_SCOPE_AGENT));
+        }
+        c = block_argmin<T>(c, sk, si, slot); // (its barrier is the one the polling waves join)
+        slot ^= 1;
+        if (sh_fail) return; // uniform: written before the barrier above
+        if (c.i == INT_MAX) {
+            if (phase == 1) { // :120 phase 1 is over: same tableau, now the min-ratio exchange
+                phase = 2;
+                iter = 0.0;
+                continue;
+            }
+            term = YALPS_UNBOUNDED; // :96
+            term_result = (double)la;
+            break;
+        }
+        const int row = c.i, owner = row % NB;
+        // ---------------- the winner's raw row (sc1 loads only) ----------------------------------
+        const double *src = d.rc_rows[par] + (size_t)owner * pitch;
+        double2 pv[J];
+#pragma unroll
+        for (int j = 0; j < J; j++) pv[j] = make_double2(ld_sc1(src + cofs[j]), ld_sc1(src + cofs[j] + 1));
+        const double rhs_row = ld_sc1(d.rc_key[par] + owner);
+        int col = la;
+        if (phase == 1) { // :123-134
+            KI e = {INFINITY, INT_MAX};
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                const int c0 = 2 * (tid + j * T);
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const double coefficient = elem(pv[j], k);
+                    if (c0 + k < n && coefficient < -precision) {
+                        const double ratio = -elem(o[j], k) / coefficient;
+                        if (ratio > -INFINITY && ki_better(-ratio, c0 + k + 1, e.k, e.i)) {
+                            e.k = -ratio;
+                            e.i = c0 + k + 1;
+                        }
+                    }
+                }
+            }
+            e = block_argmin<T>(e, sk, si, slot);
+            slot ^= 1;
+            if (e.i == INT_MAX) { // :135
+                term = YALPS_INFEASIBLE;
+                break;
+            }
+            col = e.i;
+        }
+        // ---------------- pivot (src/simplex.ts:5-39) on my registers ----------------------------
+        const int ucol = (col - 1) >> 1, ecol = (col - 1) & 1, col_tid = ucol % T, col_j = ucol / T;
+        if (tid == col_tid) { // pivot-column entries of my rows, of the objective row, the quotient
+#pragma unroll
+            for (int j = 0; j < J; j++)
+                if (j == col_j) {
+#pragma unroll
+                    for (int g = 0; g < R; g++) sh_val[g] = elem(x[g][j], ecol);
+                    sh_val[R] = elem(o[j], ecol);
+                    sh_val[R + 1] = elem(pv[j], ecol);
+                }
+        }
+        __syncthreads();
+        const double q = sh_val[R + 1], coef0 = sh_val[R];
+        unsigned nzmask = 0;
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const double v = elem(pv[j], k);
+                const bool nz = fabs(v) > 1e-16;
+                pv[j] = with_elem(pv[j], k, nz ? v / q : 0.0);
+                if (nz) nzmask |= 1u << (2 * j + k);
+            }
+        }
+        const bool nz_rhs = fabs(rhs_row) > 1e-16;
+        const double pn_rhs = nz_rhs ? rhs_row / q : 0.0;
+        const int lslot = owner == b ? row / NB : -1; // my register slot of the pivot row, if I own it
+        // the R + 2 divisions of the pivot column (one per lane of wave 0, not R+2 per lane)
+        if (tid < R + 2) sh_nq[tid] = tid == R + 1 ? 1.0 / q : -sh_val[tid] / q;
+#pragma unroll
+        for (int g = 0; g < R; g++) {
+            const double cf = sh_val[g];
+            if (g == lslot) {
+#pragma unroll
+                for (int j = 0; j < J; j++) x[g][j] = pv[j];
+            } else if (b + NB * g < h && fabs(cf) > 1e-16) { // :31
+#pragma unroll
+                for (int j = 0; j < J; j++) {
+                    if (nzmask & (1u << (2 * j))) {
+                        const double prod = cf * pv[j].x;
+                        x[g][j].x = x[g][j].x - prod;
+                    }
+                    if (nzmask & (1u << (2 * j + 1))) {
+                        const double prod = cf * pv[j].y;
+                        x[g][j].y = x[g][j].y - prod;
+                    }
+                }
+            }
+        }
+        const bool touched0 = fabs(coef0) > 1e-16;
+        if (touched0) { // my replica of the objective row gets the same update
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                if (nzmask & (1u << (2 * j))) {
+                    const double prod = coef0 * pv[j].x;
+                    o[j].x = o[j].x - prod;
+                }
+                if (nzmask & (1u << (2 * j + 1))) {
+                    const double prod = coef0 * pv[j].y;
+                    o[j].y = o[j].y - prod;
+                }
+            }
+        }
+        __syncthreads(); // sh_nq visible
+        if (tid == col_tid) { // the pivot column itself: 1/quotient in the pivot row, -coef/quotient elsewhere
+#pragma unroll
+            for (int j = 0; j < J; j++)
+                if (j == col_j) {
+#pragma unroll
+                    for (int g = 0; g < R; g++) {
+                        if (g == lslot)
+                            x[g][j] = with_elem(x[g][j], ecol, sh_nq[R + 1]);
+                        else if (b + NB * g < h && fabs(sh_val[g]) > 1e-16)
+                            x[g][j] = with_elem(x[g][j], ecol, sh_nq[g]);
+                    }
+                    if (touched0) o[j] = with_elem(o[j], ecol, sh_nq[R]);
+                }
+        }
+        if (my_live) { // RHS entry of my row
+            double my_coef = 0.0;
+#pragma unroll
+            for (int g = 0; g < R; g++)
+                if (tid == g) my_coef = sh_val[g];
+            if (tid == lslot)
+                my_rhs = pn_rhs;
+            else if (fabs(my_coef) > 1e-16 && nz_rhs) {
+                const double prod = my_coef * pn_rhs;
+                my_rhs = my_rhs - prod;
+            }
+        }
+        if (b == 0 && tid == 0) { // basis bookkeeping, :7-12, in LDS
+            int *var = sh_perm, *pos = sh_perm + d.perm_len;
+            const int leaving = var[w + row], entering = var[col];
+            var[w + row] = entering;
+            var[col] = leaving;
+            pos[leaving] = col;
+            pos[entering] = w + row;
+        }
+        iter += 1.0;
+        pivots += 1;
+        done += 1;
+        __syncthreads(); // sh_val consumed before scan() rewrites it
+        scan();
+    }
+
+    // ---------------- leave: tableau to the other buffer, state, basis ---------------------------
+    double *matB = d.mat[mbuf ^ 1];
+    double *rhsB = d.rhs[mbuf ^ 1];
+#pragma unroll
+    for (int g = 0; g < R; g++) {
+        const int r = b + NB * g;
+        if (r < h) {
+            double *mr = matB + (size_t)r * pitch;
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                const int c0 = 2 * (tid + j * T);
+                if (c0 < pitch) *reinterpret_cast<double2 *>(mr + c0) = x[g][j];
+            }
+        }
+    }
+    if (my_live) rhsB[my_r] = my_rhs;
+    if (b == 0) {
+        for (int i = tid; i < d.perm_len; i += T) {
+            d.var[i] = sh_perm[i];
+            d.pos[i] = sh_perm[d.perm_len + i];
+        }
+        if (tid == 0) {
+            if (term == YALPS_OPTIMAL) term_result = round_to_precision(my_rhs, precision); // lane 0 = row 0
+            Sout->status = term;
+            Sout->phase = phase;
+            Sout->bootstrap = 1; // the streaming kernel would have to re-scan
+            Sout->la = 0;
+            Sout->pbuf = 0;
+            Sout->mbuf = mbuf ^ 1;
+            Sout->pause = 0;
+            Sout->dec_valid = 0;
+            Sout->dec_row = 0;
+            Sout->dec_col = 0;
+            Sout->swap_valid = 0;
+            Sout->swap_row = 0;
+            Sout->swap_col = 0;
+            Sout->pad_ = 0;
+            Sout->hist_len = 0;
+            Sout->iter = iter;
+            Sout->result = term_result;
+            Sout->pivots = pivots;
+        }
+    }
+}
+
 // Applies a pending basis swap left by the last APPLY launch (single-pivot API).
 __global__ void flush_swap_kernel(Desc d, int parity) {
     YState *S = d.st + parity;
@@ -824,6 +1246,21 @@ const Variant kVariants[] = {
 };
 #undef VARIANT
 
+using ResidentFn = void (*)(Desc, int, int);
+struct RVariant {
+    int T, J, R;
+    ResidentFn fn;
+};
+#define RVARIANT(T, J, R) {T, J, R, resident_kernel<T, J, R>}
+const RVariant kResident[] = {
+    // few, fat lanes: the loop is latency-bound, and <= 8 waves per CU leave each lane 256 VGPRs
+    RVARIANT(256, 1, 4), RVARIANT(256, 1, 9), RVARIANT(256, 1, 16), RVARIANT(256, 2, 4), RVARIANT(256, 2, 9),
+    RVARIANT(256, 2, 16), RVARIANT(512, 2, 4), RVARIANT(512, 2, 9), RVARIANT(512, 2, 16), RVARIANT(512, 4, 4),
+    RVARIANT(512, 4, 9),
+};
+#undef RVARIANT
+constexpr int RESIDENT_CHUNK = 4096; // pivots per launch of the resident kernel (bounds its run time)
+
 thread_local std::string g_err;
 
 int fail(int code, const std::string &msg) {
@@ -853,6 +1290,8 @@ struct yalps_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool eager = false;
     bool nt_stores = false;
+    bool resident = true; // use the on-chip resident kernel when the tableau fits (YALPS_HIP_RESIDENT=0: never)
+    int num_cus = 256;
     int max_blocks = 256; // workgroups per launch (one per CU by default)
 };
 
@@ -862,6 +1301,8 @@ struct yalps_tableau {
     int32_t height = 0;
     int cur = 0; // tableau buffer holding the current tableau
     int shard_parity = 0;
+    RVariant rvar{0, 0, 0, nullptr}; // resident kernel variant, fn == nullptr: tableau does not fit
+    size_t rshmem = 0;
     int32_t perm_len = 0; // entries of pos / var (width + GLOBAL height)
     Variant var{};
     int nb = 1;
@@ -1018,7 +1459,9 @@ static int32_t ctx_create(int32_t device, void *ext_stream, bool adopt, yalps_ct
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
     c->eager = env_int("YALPS_HIP_EAGER", 0) != 0;
-    c->nt_stores = env_int("YALPS_HIP_NT", 1) != 0; // measured 1-2 % faster in the pivot loop at 2049^2 and 4097^2
+    c->nt_stores = env_int("YALPS_HIP_NT", 1) != 0;
+    c->resident = env_int("YALPS_HIP_RESIDENT", 1) != 0;
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; // measured 1-2 % faster in the pivot loop at 2049^2 and 4097^2
     c->max_blocks = env_int("YALPS_HIP_BLOCKS", prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
     if (c->max_blocks < 1) c->max_blocks = 1;
     if (c->max_blocks > MAX_BLOCKS) c->max_blocks = MAX_BLOCKS;
@@ -1095,6 +1538,26 @@ int32_t yalps_tableau_create(yalps_ctx *ctx, int32_t width, int32_t hcap, yalps_
         HIP_TRY(hipMalloc(&d.part_ratio[k], sizeof(Part) * MAX_BLOCKS));
         HIP_TRY(hipMalloc(&d.part_rhs[k], sizeof(Part) * MAX_BLOCKS));
     }
+    // resident (on-chip) solver: needs every workgroup co-resident (one per CU) and the rows of a
+    // workgroup in registers
+    d.perm_len = t->perm_len;
+    if (t->nb <= ctx->num_cus) {
+        const int rT = units <= 512 ? 256 : 512;
+        const int rJ = units <= 256 ? 1 : units <= 1024 ? 2 : 4;
+        for (const RVariant &v : kResident) {
+            if (units > 2048 || v.T != rT || v.J != rJ || v.R < rows_per_block) continue;
+            t->rvar = v;
+            break;
+        }
+    }
+    if (t->rvar.fn) {
+        for (int k = 0; k < 2; k++) {
+            HIP_TRY(hipMalloc(&d.rc_rows[k], sizeof(double) * (size_t)t->nb * d.pitch));
+            HIP_TRY(hipMalloc(&d.rc_key[k], sizeof(double) * (size_t)t->nb));
+            HIP_TRY(hipMalloc(&d.rc_flag[k], sizeof(unsigned long long) * 2 * (size_t)t->nb));
+        }
+        HIP_TRY(hipMalloc(&d.rc_err, sizeof(int32_t)));
+    }
     HIP_TRY(hipHostMalloc(&t->host_state, sizeof(YState) * 4, hipHostMallocDefault));
     for (int k = 0; k < 4; k++) HIP_TRY(hipEventCreateWithFlags(&t->slot_ev[k], hipEventDisableTiming));
     HIP_TRY(hipStreamSynchronize(s));
@@ -1111,7 +1574,8 @@ void yalps_tableau_destroy(yalps_tableau *t) {
         if (t->graph[k]) (void)hipGraphDestroy(t->graph[k]);
     }
     Desc &d = t->d;
-    void *bufs[] = {d.mat[0], d.mat[1], d.rhs[0], d.rhs[1], d.pos, d.var, d.st, d.cst, d.part_ratio[0], d.part_ratio[1], d.part_rhs[0], d.part_rhs[1],
+    void *bufs[] = {d.mat[0], d.mat[1], d.rhs[0], d.rhs[1], d.pos, d.var, d.st, d.cst, d.rc_rows[0], d.rc_rows[1],
+                    d.rc_key[0], d.rc_key[1], d.rc_flag[0], d.rc_flag[1], d.rc_err, d.part_ratio[0], d.part_ratio[1], d.part_rhs[0], d.part_rhs[1],
                     t->hist[0], t->hist[1]};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
@@ -1140,6 +1604,7 @@ int32_t yalps_tableau_upload(yalps_tableau *t, const double *matrix, int32_t hei
     if (t->d.nshards > 1) return fail(YALPS_E_ARG, "yalps_tableau_upload: tableau is sharded; create a new one");
     const size_t nperm = sizeof(int32_t) * (size_t)(d.w + height);
     t->perm_len = d.w + height;
+    t->d.perm_len = t->perm_len;
     HIP_TRY(hipMemcpyAsync(d.pos, pos, nperm, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d.var, var, nperm, hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -1193,6 +1658,7 @@ int32_t yalps_tableau_copy(yalps_tableau *dst, const yalps_tableau *src) {
     HIP_TRY(hipStreamSynchronize(s));
     dst->height = src->height;
     dst->perm_len = src->perm_len;
+    dst->d.perm_len = src->perm_len;
     return 0;
 }
 
@@ -1205,14 +1671,70 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
     const int which = checkCycles ? 1 : 0;
     int rc = init_state(t, precision, maxPivots, checkCycles);
     if (rc) return rc;
-    rc = ensure_graph(t, which);
-    if (rc) return rc;
     HIP_TRY(hipEventRecord(c->ev0, s));
-    // keep one batch in flight while the previous batch's state is inspected
     YState fin;
     std::memset(&fin, 0, sizeof fin);
+    bool finished = false;
+
+    // (a) the tableau fits on chip: persistent register-resident kernel, RESIDENT_CHUNK pivots per launch
+    if (!checkCycles && c->resident && t->rvar.fn && t->d.nshards == 1) {
+        const size_t shmem = sizeof(int32_t) * 2 * (size_t)t->perm_len;
+        if (shmem != t->rshmem) {
+            if (shmem > 48 * 1024)
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(t->rvar.fn),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+            t->rshmem = shmem;
+        }
+        int parity = 0;
+        int32_t *herr = reinterpret_cast<int32_t *>(&t->host_state[3]); // pinned scratch
+        for (;;) {
+            for (int k = 0; k < 2; k++)
+                HIP_TRY(hipMemsetAsync(t->d.rc_flag[k], 0, sizeof(unsigned long long) * 2 * (size_t)t->nb, s));
+            HIP_TRY(hipMemsetAsync(t->d.rc_err, 0, sizeof(int32_t), s));
+            t->rvar.fn<<<dim3(t->nb), dim3(t->rvar.T), shmem, s>>>(t->d, parity, RESIDENT_CHUNK);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(herr, t->d.rc_err, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(&t->host_state[1], t->d.st + (parity ^ 1), sizeof(YState), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            if (*herr) {
+                // a workgroup gave up waiting (grid not co-resident?): never again on this context;
+                // carry on with the streaming kernel from the last consistent state (st[parity])
+                c->resident = false;
+                YState last;
+                HIP_TRY(hipMemcpy(&last, t->d.st + parity, sizeof(YState), hipMemcpyDeviceToHost));
+                t->cur = last.mbuf;
+                if (t->cur != 0) {
+                    const Desc &d = t->d;
+                    HIP_TRY(hipMemcpyAsync(d.mat[0], d.mat[1], sizeof(double) * (size_t)d.pitch * t->height,
+                                           hipMemcpyDeviceToDevice, s));
+                    HIP_TRY(hipMemcpyAsync(d.rhs[0], d.rhs[1], sizeof(double) * (size_t)t->height,
+                                           hipMemcpyDeviceToDevice, s));
+                    t->cur = 0;
+                }
+                last.mbuf = 0;
+                last.bootstrap = 1;
+                last.la = 0;
+                last.pbuf = 0;
+                HIP_TRY(hipMemcpy(t->d.st, &last, sizeof(YState), hipMemcpyHostToDevice));
+                break;
+            }
+            if (t->host_state[1].status != RUNNING) {
+                fin = t->host_state[1];
+                finished = true;
+                break;
+            }
+            parity ^= 1;
+        }
+    }
+
+    // (b) general path: streaming kernel, one launch per pivot
+    if (!finished) {
+        rc = ensure_graph(t, which);
+        if (rc) return rc;
+    }
+    // keep one batch in flight while the previous batch's state is inspected
     int issued = 0, checked = 0;
-    for (;;) {
+    while (!finished) {
         rc = run_batch(t, which);
         if (rc) return rc;
         const int slot = issued & 3;
@@ -1336,6 +1858,8 @@ int32_t yalps_tableau_set_shard(yalps_tableau *t, int32_t rank, int32_t nranks, 
     HIP_TRY(hipMemcpyAsync(d.var, var, sizeof(int32_t) * n, hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));
     t->perm_len = (int32_t)n;
+    d.perm_len = t->perm_len;
+    t->rvar.fn = nullptr; // a shard is driven step by step
     // graphs captured for the unsharded tableau hold the old Desc
     for (int k = 0; k < 2; k++) {
         if (t->graph_exec[k]) (void)hipGraphExecDestroy(t->graph_exec[k]);
@@ -1437,4 +1961,5 @@ int32_t yalps_simplex_f64(double *matrix, int32_t width, int32_t height, int32_t
 }
 
 } // extern "C"
+
 
