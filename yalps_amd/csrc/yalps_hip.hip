@@ -953,15 +953,22 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
     unsigned epoch = 0;
     int done = 0, term = RUNNING;
     double term_result = NAN;
-    for (;;) {
-        if (done == chunk) break;
+    // (single back edge, single exit: every `stop` is a flag, so the rows stay in one set of registers)
+    bool stop = false;
+    while (!stop) {
+        if (done == chunk) {
+            stop = true;
+            continue;
+        }
         if (!(iter < max_pivots)) { // src/simplex.ts:69,109
             term = YALPS_CYCLED;
-            break;
+            stop = true;
+            continue;
         }
         if (phase == 2 && la == 0) { // :80
             term = YALPS_OPTIMAL;
-            break;
+            stop = true;
+            continue;
         }
         // ---------------- publish my candidate + its row, gather everyone's ----------------------
         candidate(phase);
@@ -1024,11 +1031,12 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
             if (phase == 1) { // :120 phase 1 is over: same tableau, now the min-ratio exchange
                 phase = 2;
                 iter = 0.0;
-                continue;
+            } else {
+                term = YALPS_UNBOUNDED; // :96
+                term_result = (double)la;
+                stop = true;
             }
-            term = YALPS_UNBOUNDED; // :96
-            term_result = (double)la;
-            break;
+            continue;
         }
         const int row = c.i, owner = row % NB;
         // ---------------- the winner's raw row (sc1 loads only) ----------------------------------
@@ -1059,7 +1067,8 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
             slot ^= 1;
             if (e.i == INT_MAX) { // :135
                 term = YALPS_INFEASIBLE;
-                break;
+                stop = true;
+                continue;
             }
             col = e.i;
         }
