@@ -887,10 +887,10 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
     if (tid == 0) sh_fail = 0;
     __syncthreads();
 
-    // my candidates for the next exchange, from the rows as they are + entering column `la`
-    int la = 0;
-    auto scan = [&]() {
-        // Dantzig pricing (src/simplex.ts:71-79) on my replica of the objective row
+    // ---- building blocks of one round ------------------------------------------------------------
+    int la = 0; // entering column of the NEXT pivot (phase 2), priced on my objective replica
+    // Dantzig pricing (src/simplex.ts:71-79) on my replica of the objective row -> la
+    auto price = [&]() __attribute__((always_inline)) {
         KI best = {INFINITY, INT_MAX};
 #pragma unroll
         for (int j = 0; j < J; j++) {
@@ -907,19 +907,11 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
         best = block_argmin<T>(best, sk, si, slot);
         slot ^= 1;
         la = best.i == INT_MAX ? 0 : best.i;
-        const int ula = (la - 1) >> 1, ela = (la - 1) & 1;
-        if (la > 0 && tid == ula % T) {
-#pragma unroll
-            for (int g = 0; g < R; g++)
-#pragma unroll
-                for (int j = 0; j < J; j++)
-                    if (j == ula / T) sh_val[g] = elem(x[g][j], ela);
-        }
-        __syncthreads();
     };
-    // lanes 0..R-1: candidate of my row of the given kind (1 = most negative RHS, 2 = min ratio),
-    // reduced over the workgroup and left in sh_ck / sh_ci / sh_cg for every lane
-    auto candidate = [&](int kind) {
+    // lanes 0..R-1: candidate of my row of the given kind (1 = most negative RHS, 2 = min ratio with
+    // the row's entry in column la taken from sh_val[lane]), reduced over the workgroup and left in
+    // sh_ck / sh_ci / sh_cg for every lane
+    auto candidate = [&](int kind) __attribute__((always_inline)) {
         KI c = {INFINITY, INT_MAX};
         if (my_live && my_r >= 1) {
             if (kind == 1) {
@@ -948,62 +940,85 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
         }
         __syncthreads();
     };
-
-    scan();
     unsigned epoch = 0;
-    int done = 0, term = RUNNING;
-    double term_result = NAN;
-    // (single back edge, single exit: every `stop` is a flag, so the rows stay in one set of registers)
-    bool stop = false;
-    while (!stop) {
-        if (done == chunk) {
-            stop = true;
-            continue;
-        }
-        if (!(iter < max_pivots)) { // src/simplex.ts:69,109
-            term = YALPS_CYCLED;
-            stop = true;
-            continue;
-        }
-        if (phase == 2 && la == 0) { // :80
-            term = YALPS_OPTIMAL;
-            stop = true;
-            continue;
-        }
-        // ---------------- publish my candidate + its row, gather everyone's ----------------------
-        candidate(phase);
+    // publish my candidate (sh_ck / sh_ci) and the data of its row (register slot sh_cg)
+    auto publish = [&]() __attribute__((always_inline)) {
         epoch++;
-        const int par = epoch & 1;
-        {
-            const int cg = sh_cg;
-            double2 v[J];
+        const int par = epoch & 1, cg = sh_cg;
+        double2 v[J];
 #pragma unroll
-            for (int j = 0; j < J; j++) v[j] = x[0][j];
+        for (int j = 0; j < J; j++) v[j] = x[0][j];
+        // v = x[cg] as a chain of register selects.  The empty asm keeps hipcc from rewriting the chain
+        // into a dynamically indexed load, which would move all my rows from registers to scratch.
 #pragma unroll
-            for (int g = 1; g < R; g++)
-                if (g == cg) {
-#pragma unroll
-                    for (int j = 0; j < J; j++) v[j] = x[g][j];
-                }
-            double *dst = d.rc_rows[par] + (size_t)b * pitch;
+        for (int g = 1; g < R; g++) {
 #pragma unroll
             for (int j = 0; j < J; j++) {
-                const int c0 = 2 * (tid + j * T);
-                if (c0 < pitch) {
-                    st_sc1(dst + c0, v[j].x);
-                    st_sc1(dst + c0 + 1, v[j].y);
-                }
+                double ax = x[g][j].x, ay = x[g][j].y;
+                asm volatile("" : "+v"(ax), "+v"(ay));
+                v[j].x = g == cg ? ax : v[j].x;
+                v[j].y = g == cg ? ay : v[j].y;
             }
-            if (tid == cg) st_sc1(d.rc_key[par] + b, my_rhs); // the candidate row's RHS entry (lane cg)
-            if (tid == 0) // the key travels next to the flag: one 16-byte record per workgroup
-                __hip_atomic_store(d.rc_flag[par] + 2 * b, (unsigned long long)__double_as_longlong(sh_ck),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains ...
-            __syncthreads();                                  // ... before ONE lane raises the flag
-            if (tid == 0)
-                __hip_atomic_store(d.rc_flag[par] + 2 * b + 1, ((unsigned long long)epoch << 32) | (unsigned)sh_ci,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        double *dst = d.rc_rows[par] + (size_t)b * pitch;
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            const int c0 = 2 * (tid + j * T);
+            if (c0 < pitch) {
+                st_sc1(dst + c0, v[j].x);
+                st_sc1(dst + c0 + 1, v[j].y);
+            }
+        }
+        if (tid == cg) st_sc1(d.rc_key[par] + b, my_rhs); // the candidate row's RHS entry (lane cg)
+        if (tid == 0) // the key travels next to the flag: one 16-byte record per workgroup
+            __hip_atomic_store(d.rc_flag[par] + 2 * b, (unsigned long long)__double_as_longlong(sh_ck), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains ...
+        __syncthreads();                                  // ... before ONE lane raises the flag
+        if (tid == 0)
+            __hip_atomic_store(d.rc_flag[par] + 2 * b + 1, ((unsigned long long)epoch << 32) | (unsigned)sh_ci,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // entries of my rows in column la, as the rows are now -> sh_val[0..R)
+    auto column_la = [&]() __attribute__((always_inline)) {
+        const int ula = (la - 1) >> 1, ela = (la - 1) & 1;
+        if (la > 0 && tid == ula % T) {
+#pragma unroll
+            for (int g = 0; g < R; g++)
+#pragma unroll
+                for (int j = 0; j < J; j++)
+                    if (j == ula / T) sh_val[g] = elem(x[g][j], ela);
+        }
+        __syncthreads();
+    };
+    int done = 0, term = RUNNING;
+    double term_result = NAN;
+    bool stop = false;
+    // loop bound, optimality: checked before every exchange (src/simplex.ts:69,109 and :80)
+    auto check = [&]() __attribute__((always_inline)) {
+        if (done == chunk) {
+            stop = true;
+        } else if (!(iter < max_pivots)) {
+            term = YALPS_CYCLED;
+            stop = true;
+        } else if (phase == 2 && la == 0) {
+            term = YALPS_OPTIMAL;
+            stop = true;
+        }
+    };
+
+    // first round: candidates from the tableau as loaded
+    price();
+    column_la();
+    check();
+    if (!stop) {
+        candidate(phase);
+        publish();
+    }
+    // (single back edge, single exit: every `stop` is a flag, so the rows stay in one set of registers)
+    while (!stop) {
+        // ---------------- gather everyone's candidate -------------------------------------------
+        const int par = epoch & 1;
         KI c = {INFINITY, INT_MAX};
         if (tid < NB) {
             // The key word was stored and drained before the flag word of the same 16-byte record,
@@ -1031,6 +1046,12 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
             if (phase == 1) { // :120 phase 1 is over: same tableau, now the min-ratio exchange
                 phase = 2;
                 iter = 0.0;
+                check();
+                if (!stop) {
+                    column_la(); // my rows are complete here: their entries of column la
+                    candidate(2);
+                    publish();
+                }
             } else {
                 term = YALPS_UNBOUNDED; // :96
                 term_result = (double)la;
@@ -1073,6 +1094,9 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
             col = e.i;
         }
         // ---------------- pivot (src/simplex.ts:5-39) on my registers ----------------------------
+        // Order: everything the NEXT exchange needs first (objective replica -> la, my rows' entries
+        // of column la and RHS -> my candidate, that one row), publish, and only then the other rows:
+        // their elimination overlaps the time the flags take to travel.
         const int ucol = (col - 1) >> 1, ecol = (col - 1) & 1, col_tid = ucol % T, col_j = ucol / T;
         if (tid == col_tid) { // pivot-column entries of my rows, of the objective row, the quotient
 #pragma unroll
@@ -1086,6 +1110,9 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
         }
         __syncthreads();
         const double q = sh_val[R + 1], coef0 = sh_val[R];
+        double cf[R]; // uniform: pivot-column entry of each of my rows
+#pragma unroll
+        for (int g = 0; g < R; g++) cf[g] = sh_val[g];
         unsigned nzmask = 0;
 #pragma unroll
         for (int j = 0; j < J; j++) {
@@ -1098,64 +1125,15 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
             }
         }
         const bool nz_rhs = fabs(rhs_row) > 1e-16;
-        const double pn_rhs = nz_rhs ? rhs_row / q : 0.0;
         const int lslot = owner == b ? row / NB : -1; // my register slot of the pivot row, if I own it
         // the R + 2 divisions of the pivot column (one per lane of wave 0, not R+2 per lane)
         if (tid < R + 2) sh_nq[tid] = tid == R + 1 ? 1.0 / q : -sh_val[tid] / q;
-#pragma unroll
-        for (int g = 0; g < R; g++) {
-            const double cf = sh_val[g];
-            if (g == lslot) {
-#pragma unroll
-                for (int j = 0; j < J; j++) x[g][j] = pv[j];
-            } else if (b + NB * g < h && fabs(cf) > 1e-16) { // :31
-#pragma unroll
-                for (int j = 0; j < J; j++) {
-                    if (nzmask & (1u << (2 * j))) {
-                        const double prod = cf * pv[j].x;
-                        x[g][j].x = x[g][j].x - prod;
-                    }
-                    if (nzmask & (1u << (2 * j + 1))) {
-                        const double prod = cf * pv[j].y;
-                        x[g][j].y = x[g][j].y - prod;
-                    }
-                }
-            }
-        }
-        const bool touched0 = fabs(coef0) > 1e-16;
-        if (touched0) { // my replica of the objective row gets the same update
-#pragma unroll
-            for (int j = 0; j < J; j++) {
-                if (nzmask & (1u << (2 * j))) {
-                    const double prod = coef0 * pv[j].x;
-                    o[j].x = o[j].x - prod;
-                }
-                if (nzmask & (1u << (2 * j + 1))) {
-                    const double prod = coef0 * pv[j].y;
-                    o[j].y = o[j].y - prod;
-                }
-            }
-        }
-        __syncthreads(); // sh_nq visible
-        if (tid == col_tid) { // the pivot column itself: 1/quotient in the pivot row, -coef/quotient elsewhere
-#pragma unroll
-            for (int j = 0; j < J; j++)
-                if (j == col_j) {
-#pragma unroll
-                    for (int g = 0; g < R; g++) {
-                        if (g == lslot)
-                            x[g][j] = with_elem(x[g][j], ecol, sh_nq[R + 1]);
-                        else if (b + NB * g < h && fabs(sh_val[g]) > 1e-16)
-                            x[g][j] = with_elem(x[g][j], ecol, sh_nq[g]);
-                    }
-                    if (touched0) o[j] = with_elem(o[j], ecol, sh_nq[R]);
-                }
-        }
-        if (my_live) { // RHS entry of my row
+        if (my_live) { // RHS entry of my row (:33 at column 0)
+            const double pn_rhs = nz_rhs ? rhs_row / q : 0.0;
             double my_coef = 0.0;
 #pragma unroll
             for (int g = 0; g < R; g++)
-                if (tid == g) my_coef = sh_val[g];
+                if (tid == g) my_coef = cf[g];
             if (tid == lslot)
                 my_rhs = pn_rhs;
             else if (fabs(my_coef) > 1e-16 && nz_rhs) {
@@ -1163,7 +1141,88 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
                 my_rhs = my_rhs - prod;
             }
         }
-        if (b == 0 && tid == 0) { // basis bookkeeping, :7-12, in LDS
+        const bool touched0 = fabs(coef0) > 1e-16;
+        if (touched0) { // my replica of the objective row (branch-free over the lane's columns)
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                const double px = coef0 * pv[j].x, py = coef0 * pv[j].y;
+                const double nx = o[j].x - px, ny = o[j].y - py;
+                o[j].x = (nzmask & (1u << (2 * j))) ? nx : o[j].x;
+                o[j].y = (nzmask & (1u << (2 * j + 1))) ? ny : o[j].y;
+            }
+        }
+        __syncthreads(); // sh_nq visible; sh_val (pivot column) consumed
+        if (touched0 && tid == col_tid) {
+#pragma unroll
+            for (int j = 0; j < J; j++)
+                if (j == col_j) o[j] = with_elem(o[j], ecol, sh_nq[R]);
+        }
+        // my rows, fully, as pivot() leaves them: slot `only` (only_it = true) or all slots but it
+        auto finish_rows = [&](int only, bool only_it) __attribute__((always_inline)) {
+#pragma unroll
+            for (int g = 0; g < R; g++) { // (g must stay a compile-time index: the rows are registers)
+            if ((g == only) != only_it) continue;
+            if (g == lslot) {
+#pragma unroll
+                for (int j = 0; j < J; j++) {
+                    x[g][j] = pv[j];
+                    if (tid == col_tid && j == col_j) x[g][j] = with_elem(x[g][j], ecol, sh_nq[R + 1]); // :25
+                }
+            } else if (b + NB * g < h && fabs(cf[g]) > 1e-16) { // :31 (uniform per row)
+#pragma unroll
+                for (int j = 0; j < J; j++) {
+                    const double px = cf[g] * pv[j].x, py = cf[g] * pv[j].y;
+                    const double nx = x[g][j].x - px, ny = x[g][j].y - py;
+                    x[g][j].x = (nzmask & (1u << (2 * j))) ? nx : x[g][j].x;
+                    x[g][j].y = (nzmask & (1u << (2 * j + 1))) ? ny : x[g][j].y;
+                    if (tid == col_tid && j == col_j) x[g][j] = with_elem(x[g][j], ecol, sh_nq[g]); // :36
+                }
+            }
+            }
+        };
+        iter += 1.0;
+        pivots += 1;
+        done += 1;
+        price(); // la of the next pivot, from the updated objective replica
+        check();
+        if (!stop) {
+            if (phase == 2) {
+                // my rows' entries of column la AFTER this pivot, computed by the lane that holds them
+                const int ula = (la - 1) >> 1, ela = (la - 1) & 1;
+                if (tid == ula % T) {
+#pragma unroll
+                    for (int j = 0; j < J; j++)
+                        if (j == ula / T) {
+                            const double p = elem(pv[j], ela);
+                            const bool nz = (nzmask >> (2 * j + ela)) & 1u;
+#pragma unroll
+                            for (int g = 0; g < R; g++) {
+                                double v = elem(x[g][j], ela);
+                                if (g == lslot)
+                                    v = la == col ? sh_nq[R + 1] : p;
+                                else if (b + NB * g < h && fabs(cf[g]) > 1e-16) {
+                                    if (la == col)
+                                        v = sh_nq[g];
+                                    else if (nz) {
+                                        const double prod = cf[g] * p;
+                                        v = v - prod;
+                                    }
+                                }
+                                sh_val[g] = v;
+                            }
+                        }
+                }
+                __syncthreads();
+            }
+            candidate(phase);
+            const int cg = sh_cg;
+            finish_rows(cg, true);
+            publish();
+            finish_rows(cg, false);
+        } else {
+            finish_rows(-1, false);
+        }
+        if (b == 0 && tid == 0) { // basis bookkeeping, :7-12, in LDS (off the critical path)
             int *var = sh_perm, *pos = sh_perm + d.perm_len;
             const int leaving = var[w + row], entering = var[col];
             var[w + row] = entering;
@@ -1171,11 +1230,7 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
             pos[leaving] = col;
             pos[entering] = w + row;
         }
-        iter += 1.0;
-        pivots += 1;
-        done += 1;
-        __syncthreads(); // sh_val consumed before scan() rewrites it
-        scan();
+        __syncthreads(); // sh_val / sh_nq consumed before the next round rewrites them
     }
 
     // ---------------- leave: tableau to the other buffer, state, basis ---------------------------
@@ -1562,7 +1617,7 @@ int32_t yalps_tableau_create(yalps_ctx *ctx, int32_t width, int32_t hcap, yalps_
     if (t->rvar.fn) {
         for (int k = 0; k < 2; k++) {
             HIP_TRY(hipMalloc(&d.rc_rows[k], sizeof(double) * (size_t)t->nb * d.pitch));
-            HIP_TRY(hipMalloc(&d.rc_key[k], sizeof(double) * (size_t)t->nb));
+            HIP_TRY(hipMalloc(&d.rc_key[k], sizeof(double) * ((size_t)t->nb + 8)));
             HIP_TRY(hipMalloc(&d.rc_flag[k], sizeof(unsigned long long) * 2 * (size_t)t->nb));
         }
         HIP_TRY(hipMalloc(&d.rc_err, sizeof(int32_t)));
@@ -1970,5 +2025,6 @@ int32_t yalps_simplex_f64(double *matrix, int32_t width, int32_t height, int32_t
 }
 
 } // extern "C"
+
 
 
