@@ -16,15 +16,14 @@ copy of the tableau that is already resident in HBM.  value = pivots executed / 
          a step = --pivots-per-step pivots of that solve; strong scaling.
 
 Extra objects on the JSON line (N == 1 / rank 0 only):
-  roofline      the dominant (only) kernel, pivot_kernel: ONE launch = one complete pivot
-                (selection + pivot-row normalise + rank-1 elimination of the whole tableau).
-                achieved = algorithmic bytes per launch (SURVEY.md 8d:
-                16*(h-1)*w + 16*w + 8*(h-1) + 8*(w-1) + 16*(h-1)) / average launch duration, where
-                the duration is HIP-event time over the timed region's pivot loops on the
-                library's own stream divided by the pivots executed (includes launch gaps and the
-                few no-op launches after termination, i.e. it is slightly pessimistic).
-  apply_only    the same kernel in APPLY mode (fixed pivot, no selection) launched back to back,
-                HIP events: isolates the elimination from the selection chain.
+  roofline      the dominant (only) kernel of the timed region.  At 2049^2 the tableau fits on chip
+                and that is resident_kernel: ONE launch = up to 4096 complete pivots (selection,
+                pivot-row normalise, rank-1 elimination) on a register-resident tableau.  achieved =
+                algorithmic bytes per launch (per pivot 16*(h-1)*w + 16*w + 8*(h-1) +
+                8*(w-1) + 16*(h-1), times the pivots of the launch) / average launch duration from
+                HIP events on the library's stream over the timed region.
+  streaming_apply_only  the general HBM-streaming kernel (pivot_kernel) in APPLY mode, fixed pivot,
+                back-to-back launches, HIP events (what a tableau that does not fit on chip gets).
   cpu_baseline  the CPU oracle (scalar C restatement of the reference, 1 thread) timed on the
                 same LP on this box's host cores.
 """
@@ -47,15 +46,19 @@ def algorithmic_bytes_per_pivot(h, w):
     return 16 * (h - 1) * w + 16 * w + 8 * (h - 1) + 8 * (w - 1) + 16 * (h - 1)
 
 
-def measured_traffic(size):
+def measured_traffic(size, resident, pivots_per_launch):
     """HBM bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, corrected as
     MI355X_MICROARCH.md prescribes), collected in separate rocprofv3 --pmc passes of this same
     workload and committed under profiles/ -- bench.py cannot run the profiler on itself."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    name = "r01_pmc_traffic_resident.json" if resident else "r01_pmc_traffic.json"
+    path = os.path.join(ROOT, "profiles", name)
     if size != 2048 or not os.path.exists(path):
         return None
     with open(path) as f:
-        return json.load(f)["traffic_bytes_per_launch"]
+        rec = json.load(f)
+    if resident:
+        return rec["traffic_bytes_per_pivot"] * pivots_per_launch
+    return rec["traffic_bytes_per_launch"]
 
 
 def cpu_baseline(M, N, seed, budget_pivots):
@@ -163,17 +166,29 @@ def main():
                        "pivots_per_step": npiv, "objective_cell": result},
         }
         if world == 1:
-            us = 1e3 * gpu_ms / pivots
-            ach = bpp / (us * 1e-6) / 1e9
-            out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK_GBPS, "traffic": measured_traffic(args.size),
-                               "kernel": "pivot_kernel<1024,1,9,9>",
-                               "avg_us": us, "bytes_per_launch": bpp,
-                               "note": "one launch = one pivot; HIP events over the timed pivot loops / pivots"}
+            info = work.info()
+            resident = info["last_path"] == "resident"
+            launches = int(info["last_resident_launches"]) if resident else npiv  # per step
+            us_pivot = 1e3 * gpu_ms / pivots
+            us_launch = 1e3 * gpu_ms / (launches * args.steps)
+            bytes_launch = bpp * npiv / launches
+            ach = bytes_launch / (us_launch * 1e-6) / 1e9
+            out["roofline"] = {
+                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+                "traffic": measured_traffic(args.size, resident, bytes_launch / bpp),
+                "kernel": info["resident"].split(" ")[0] if resident else info["streaming"],
+                "launches_per_step": launches, "avg_us": us_launch, "bytes_per_launch": bytes_launch,
+                "us_per_pivot": us_pivot,
+                "note": ("persistent kernel: one launch = up to %s pivots with the tableau resident in registers; "
+                         "algorithmic bytes (SURVEY 8d, 16*h*w per pivot) / HIP-event time. frac > 1 means faster "
+                         "than streaming the tableau through HBM could ever be; real HBM traffic is `traffic`."
+                         % info.get("chunk", "?")) if resident else
+                        "one launch = one pivot; HIP events over the timed pivot loops / pivots"}
             work.copy_from(pristine)
             us_apply = work.bench_sweep(h // 2, w // 2, args.sweep_launches)
-            out["apply_only"] = {"avg_us": us_apply, "achieved_GBps": bpp / (us_apply * 1e-6) / 1e9,
-                                 "note": "pivot_kernel in APPLY mode, fixed pivot, back-to-back launches"}
+            out["streaming_apply_only"] = {
+                "kernel": info["streaming"], "avg_us": us_apply, "achieved_GBps": bpp / (us_apply * 1e-6) / 1e9,
+                "note": "the general (HBM-streaming) kernel in APPLY mode, fixed pivot, back-to-back launches"}
             if args.cpu_pivots > 0:
                 out["cpu_baseline"] = cpu_baseline(M, N, seed, args.cpu_pivots)
     work.close()

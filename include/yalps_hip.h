@@ -91,6 +91,8 @@ int32_t yalps_tableau_download_rhs(yalps_tableau *t, double *col0);
 /* HBM -> HBM copy of matrix + permutations + height (same width; dst capacity >= src height). */
 int32_t yalps_tableau_copy(yalps_tableau *dst, const yalps_tableau *src);
 int32_t yalps_tableau_height(const yalps_tableau *t);
+/* Which kernels this tableau uses and which path the last solve took (text, for benchmarks). */
+int32_t yalps_tableau_info(const yalps_tableau *t, char *buf, int32_t len);
 
 /* Run the two-phase simplex on the resident tableau (in place).  gpu_ms_out (optional) =
  * HIP-event time of the whole pivot loop on the context's stream. */

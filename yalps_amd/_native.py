@@ -21,7 +21,7 @@ SYMBOLS = (
     "yalps_tableau_download", "yalps_tableau_download_rhs", "yalps_tableau_copy", "yalps_tableau_height",
     "yalps_tableau_solve", "yalps_tableau_pivot", "yalps_tableau_bench_sweep", "yalps_dense_lp_f64",
     "yalps_round_to_precision", "yalps_ctx_create_on_stream", "yalps_tableau_set_shard", "yalps_shard_slot_doubles",
-    "yalps_shard_begin", "yalps_shard_select", "yalps_shard_apply", "yalps_shard_poll",
+    "yalps_shard_begin", "yalps_shard_select", "yalps_shard_apply", "yalps_shard_poll", "yalps_tableau_info",
 )
 
 
@@ -79,6 +79,8 @@ def lib():
         L.yalps_tableau_copy.argtypes = [vp, vp]
         L.yalps_tableau_height.restype = C.c_int32
         L.yalps_tableau_height.argtypes = [vp]
+        L.yalps_tableau_info.restype = C.c_int32
+        L.yalps_tableau_info.argtypes = [vp, C.c_char_p, C.c_int32]
         L.yalps_tableau_solve.restype = C.c_int32
         L.yalps_tableau_solve.argtypes = [vp, C.c_double, C.c_double, C.c_int32, f64p, C.POINTER(C.c_int64),
                                           C.POINTER(C.c_float)]
@@ -175,6 +177,11 @@ class DeviceTableau:
         st = check(lib().yalps_tableau_solve(self.handle, precision, float(max_pivots), int(bool(check_cycles)),
                                              C.byref(res), C.byref(npiv), C.byref(ms)))
         return STATUS[st], res.value, npiv.value, ms.value
+
+    def info(self):
+        buf = C.create_string_buffer(512)
+        check(lib().yalps_tableau_info(self.handle, buf, 512))
+        return dict(kv.split("=", 1) for kv in buf.value.decode().split(" ") if "=" in kv)
 
     def pivot(self, row, col):
         check(lib().yalps_tableau_pivot(self.handle, row, col))

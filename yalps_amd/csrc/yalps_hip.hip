@@ -1366,6 +1366,8 @@ struct yalps_tableau {
     int cur = 0; // tableau buffer holding the current tableau
     int shard_parity = 0;
     RVariant rvar{0, 0, 0, nullptr}; // resident kernel variant, fn == nullptr: tableau does not fit
+    int last_path = 0;               // what the last solve ran: 1 resident, 2 streaming, 3 both
+    int64_t last_launches = 0;       // kernel launches of the last solve that did work (resident: chunks)
     size_t rshmem = 0;
     int32_t perm_len = 0; // entries of pos / var (width + GLOBAL height)
     Variant var{};
@@ -1651,6 +1653,19 @@ void yalps_tableau_destroy(yalps_tableau *t) {
 
 int32_t yalps_tableau_height(const yalps_tableau *t) { return t ? t->height : 0; }
 
+int32_t yalps_tableau_info(const yalps_tableau *t, char *buf, int32_t len) {
+    if (!t || !buf || len < 1) return fail(YALPS_E_ARG, "yalps_tableau_info: bad argument");
+    char res[96] = "none";
+    if (t->rvar.fn)
+        std::snprintf(res, sizeof res, "resident_kernel<%d,%d,%d> chunk=%d", t->rvar.T, t->rvar.J, t->rvar.R, RESIDENT_CHUNK);
+    std::snprintf(buf, (size_t)len,
+                  "streaming=pivot_kernel<%d,%d,%d> workgroups=%d resident=%s last_path=%s last_resident_launches=%lld",
+                  t->var.T, t->var.J, t->var.R, t->nb, res,
+                  t->last_path == 1 ? "resident" : t->last_path == 2 ? "streaming" : t->last_path == 3 ? "resident+streaming" : "none",
+                  (long long)(t->last_path & 1 ? t->last_launches : 0));
+    return 0;
+}
+
 int32_t yalps_tableau_upload(yalps_tableau *t, const double *matrix, int32_t height, const int32_t *pos,
                              const int32_t *var) {
     if (!t || !matrix || !pos || !var) return fail(YALPS_E_ARG, "yalps_tableau_upload: NULL argument");
@@ -1739,6 +1754,8 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
     YState fin;
     std::memset(&fin, 0, sizeof fin);
     bool finished = false;
+    t->last_path = 0;
+    t->last_launches = 0;
 
     // (a) the tableau fits on chip: persistent register-resident kernel, RESIDENT_CHUNK pivots per launch
     if (!checkCycles && c->resident && t->rvar.fn && t->d.nshards == 1) {
@@ -1756,6 +1773,8 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
                 HIP_TRY(hipMemsetAsync(t->d.rc_flag[k], 0, sizeof(unsigned long long) * 2 * (size_t)t->nb, s));
             HIP_TRY(hipMemsetAsync(t->d.rc_err, 0, sizeof(int32_t), s));
             t->rvar.fn<<<dim3(t->nb), dim3(t->rvar.T), shmem, s>>>(t->d, parity, RESIDENT_CHUNK);
+            t->last_path |= 1;
+            t->last_launches++;
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(herr, t->d.rc_err, sizeof(int32_t), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipMemcpyAsync(&t->host_state[1], t->d.st + (parity ^ 1), sizeof(YState), hipMemcpyDeviceToHost, s));
@@ -1795,6 +1814,7 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
     if (!finished) {
         rc = ensure_graph(t, which);
         if (rc) return rc;
+        t->last_path |= 2;
     }
     // keep one batch in flight while the previous batch's state is inspected
     int issued = 0, checked = 0;
