@@ -830,6 +830,36 @@ __device__ __forceinline__ double ld_sc1(const double *p) {
                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
+// 16-byte forms (one instruction per lane unit).  hipcc does not count inline-asm memory operations:
+// the store is covered by the publisher's explicit s_waitcnt vmcnt(0), the load waits inside its
+// own statement (CDNA guide 5.7, form (i)).
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st16_sc1(double *p, double2 v) {
+    v2f64 t = {v.x, v.y};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+}
+template <int J>
+__device__ __forceinline__ void ld16_sc1(double2 (&out)[J], const double *base, const int (&ofs)[J]) {
+    static_assert(J == 1 || J == 2 || J == 4, "lane units per row");
+    v2f64 t[J];
+    if constexpr (J == 1) {
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(t[0]) : "v"(base + ofs[0]) : "memory");
+    } else if constexpr (J == 2) {
+        asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(t[0]), "=&v"(t[1])
+                     : "v"(base + ofs[0]), "v"(base + ofs[1])
+                     : "memory");
+    } else {
+        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
+                     "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3])
+                     : "v"(base + ofs[0]), "v"(base + ofs[1]), "v"(base + ofs[2]), "v"(base + ofs[3])
+                     : "memory");
+    }
+#pragma unroll
+    for (int j = 0; j < J; j++) out[j] = make_double2(t[j].x, t[j].y);
+}
+
 template <int T, int J, int R>
 __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chunk) {
     __shared__ double sk[2][16];
@@ -964,10 +994,7 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
 #pragma unroll
         for (int j = 0; j < J; j++) {
             const int c0 = 2 * (tid + j * T);
-            if (c0 < pitch) {
-                st_sc1(dst + c0, v[j].x);
-                st_sc1(dst + c0 + 1, v[j].y);
-            }
+            if (c0 < pitch) st16_sc1(dst + c0, v[j]);
         }
         if (tid == cg) st_sc1(d.rc_key[par] + b, my_rhs); // the candidate row's RHS entry (lane cg)
         if (tid == 0) // the key travels next to the flag: one 16-byte record per workgroup
@@ -1062,10 +1089,9 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
         const int row = c.i, owner = row % NB;
         // ---------------- the winner's raw row (sc1 loads only) ----------------------------------
         const double *src = d.rc_rows[par] + (size_t)owner * pitch;
-        double2 pv[J];
-#pragma unroll
-        for (int j = 0; j < J; j++) pv[j] = make_double2(ld_sc1(src + cofs[j]), ld_sc1(src + cofs[j] + 1));
         const double rhs_row = ld_sc1(d.rc_key[par] + owner);
+        double2 pv[J];
+        ld16_sc1<J>(pv, src, cofs);
         int col = la;
         if (phase == 1) { // :123-134
             KI e = {INFINITY, INT_MAX};
