@@ -128,6 +128,27 @@ int32_t yalps_shard_select(yalps_tableau *t, double *send_dev);
 int32_t yalps_shard_apply(yalps_tableau *t, const double *gathered_dev);
 int32_t yalps_shard_poll(yalps_tableau *t, int32_t *status_out, double *result_out, int64_t *pivots_out);
 
+/* ---- batched branch-and-cut node evaluation (BASELINE config 4) ---------------
+ * src/branchAndCut.ts:126-127 evaluates every node as simplex(applyCuts(root, cuts)); nodes are
+ * independent given the root.  A batch keeps the root's optimal tableau resident, builds each
+ * node's tableau on the device (applyCuts, :22-61: one row per cut (sign, variable, value)) and
+ * solves `count` nodes concurrently, one workgroup per node.  Cuts of node i are entries
+ * [cut_offsets[i], cut_offsets[i+1]) of the three cut arrays.  checkCycles is not available here. */
+typedef struct yalps_batch yalps_batch;
+int32_t yalps_batch_create(yalps_ctx *ctx, int32_t width, int32_t root_height, int32_t max_cuts,
+                           int32_t max_nodes, yalps_batch **out);
+void yalps_batch_destroy(yalps_batch *b);
+/* Host -> HBM: the root tableau AFTER its own simplex() (row-major width*root_height) + permutations. */
+int32_t yalps_batch_set_root(yalps_batch *b, const double *matrix, const int32_t *positionOfVariable,
+                             const int32_t *variableAtPosition);
+int32_t yalps_batch_solve(yalps_batch *b, int32_t count, const int32_t *cut_offsets, const int32_t *cut_sign,
+                          const int32_t *cut_variable, const double *cut_value, double precision,
+                          double maxPivots, int32_t *status_out, double *result_out, int64_t *pivots_out,
+                          float *gpu_ms_out);
+/* Node `node` of the last batch, `height` = root_height + its number of cuts; NULL pointers are skipped. */
+int32_t yalps_batch_download(yalps_batch *b, int32_t node, int32_t height, double *matrix, double *col0,
+                             int32_t *positionOfVariable, int32_t *variableAtPosition);
+
 /* ---- synthetic input of the headline benchmark ---------------------------------------------
  * dense-LP(M,N,seed): fills a (M+1) x (N+1) row-major tableau with the
  * reference test-suite's PRNG stream (tests/helpers/util.ts:20-41).  Host-side, deterministic. */

@@ -1,0 +1,96 @@
+"""Batched branch-and-cut node evaluation on the GPU (BASELINE config 4):
+node-level bit parity with the oracle, and the batched driver against the one-node-at-a-time
+driver and the reference test-suite's expected results."""
+import numpy as np
+import pytest
+
+from tests import _cases as K
+from tests import _golden as G
+from yalps_amd import branch_and_cut as BC
+from yalps_amd import model as M
+from yalps_amd import solve as S
+
+pytestmark = pytest.mark.gpu
+INTEGER_CASES = [n for n in K.names() if K.load(n)["model"].get("integers") or K.load(n)["model"].get("binaries")]
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from yalps_amd import _native
+    assert _native.lib().yalps_device_count() >= 1
+    return _native
+
+
+def _collect_nodes(oracle, tabmod, init_result, options, limit):
+    """Runs the sequential driver with the oracle and records the cut list of every node it evaluates."""
+    from tests.test_host_model import oracle_backend
+    base = oracle_backend(oracle)
+    seen = []
+
+    def spy(tableau, opt):
+        extra = tableau.height - tabmod.tableau.height
+        seen.append(extra)
+        return base(tableau, opt)
+
+    nodes = []
+    orig = BC.apply_cuts
+
+    def record(tableau, buf, cuts):
+        if len(nodes) < limit:
+            nodes.append(tuple(cuts))
+        return orig(tableau, buf, cuts)
+
+    BC.apply_cuts = record
+    try:
+        BC.branch_and_cut(spy, tabmod, init_result, options)
+    finally:
+        BC.apply_cuts = orig
+    return nodes
+
+
+@pytest.mark.parametrize("name", ["Knapsack 1", "Large Farm MIP", "Fancy Stock Cutting Problem", "Integer Sports Complex Problem"])
+def test_batch_nodes_match_oracle(nat, oracle, name):
+    from tests.test_host_model import oracle_backend
+    case = K.load(name)
+    opt = case["options"]
+    tabmod = M.tableau_model(case["model"])
+    status, result = oracle_backend(oracle)(tabmod.tableau, opt)
+    assert status == "optimal"
+    nodes = _collect_nodes(oracle, tabmod, result, opt, 48)
+    assert nodes
+    t = tabmod.tableau
+    ctx = nat.Context(0)
+    batch = nat.NodeBatch(ctx, t.width, t.height, 2 * len(tabmod.integers), len(nodes))
+    try:
+        batch.set_root(t.matrix, t.position_of_variable, t.variable_at_position)
+        st, res, piv, heights, _ = batch.solve(nodes, opt["precision"], opt["maxPivots"])
+        buf = (np.zeros(t.matrix.size + 2 * len(tabmod.integers) * t.width), np.zeros(t.width + t.height + 2 * len(tabmod.integers), np.int32),
+               np.zeros(t.width + t.height + 2 * len(tabmod.integers), np.int32))
+        for i, cuts in enumerate(nodes):
+            cur = BC.apply_cuts(t, buf, cuts)
+            m, pos, var = cur.matrix.copy(), cur.position_of_variable.copy(), cur.variable_at_position.copy()
+            est, eres, epiv, _ = oracle.simplex(m, cur.width, cur.height, pos, var, precision=opt["precision"],
+                                                max_pivots=opt["maxPivots"])
+            assert (st[i], int(piv[i]), int(heights[i])) == (est, epiv, cur.height), (i, cuts)
+            assert G.same_number(float(res[i]), eres)
+            gm, col0, gpos, gvar = batch.download(i, cur.height, matrix=True)
+            assert np.array_equal(gm.view(np.int64), m.view(np.int64)), (i, cuts)
+            assert np.array_equal(col0.view(np.int64), m.reshape(cur.height, cur.width)[:, 0].view(np.int64))
+            assert np.array_equal(gpos, pos) and np.array_equal(gvar, var)
+    finally:
+        batch.close()
+        ctx.close()
+
+
+@pytest.mark.parametrize("name", INTEGER_CASES)
+def test_batched_solve_equals_sequential(nat, name):
+    case = K.load(name)
+    if case["options"].get("checkCycles"):
+        pytest.skip("checkCycles uses the one-node-at-a-time path")
+    stats = {}
+    a = S.solve(case["model"], case["options"], node_batch=32, stats=stats)
+    b = S.solve(case["model"], case["options"])
+    assert a["status"] == b["status"] and G.same_number(a["result"], b["result"]) and a["variables"] == b["variables"]
+    assert K.valid_solution_and_status(a, case["expected"], case["model"], case["options"])
+    if stats:
+        assert stats["nodes_used"] <= stats["nodes_evaluated"]

@@ -22,6 +22,7 @@ SYMBOLS = (
     "yalps_tableau_solve", "yalps_tableau_pivot", "yalps_tableau_bench_sweep", "yalps_dense_lp_f64",
     "yalps_round_to_precision", "yalps_ctx_create_on_stream", "yalps_tableau_set_shard", "yalps_shard_slot_doubles",
     "yalps_shard_begin", "yalps_shard_select", "yalps_shard_apply", "yalps_shard_poll", "yalps_tableau_info",
+    "yalps_batch_create", "yalps_batch_destroy", "yalps_batch_set_root", "yalps_batch_solve", "yalps_batch_download",
 )
 
 
@@ -63,6 +64,17 @@ def lib():
         L.yalps_shard_apply.argtypes = [vp, vp]
         L.yalps_shard_poll.restype = C.c_int32
         L.yalps_shard_poll.argtypes = [vp, C.POINTER(C.c_int32), f64p, C.POINTER(C.c_int64)]
+        L.yalps_batch_create.restype = C.c_int32
+        L.yalps_batch_create.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
+        L.yalps_batch_destroy.restype = None
+        L.yalps_batch_destroy.argtypes = [vp]
+        L.yalps_batch_set_root.restype = C.c_int32
+        L.yalps_batch_set_root.argtypes = [vp, vp, vp, vp]
+        L.yalps_batch_solve.restype = C.c_int32
+        L.yalps_batch_solve.argtypes = [vp, C.c_int32, vp, vp, vp, vp, C.c_double, C.c_double, vp, vp, vp,
+                                        C.POINTER(C.c_float)]
+        L.yalps_batch_download.restype = C.c_int32
+        L.yalps_batch_download.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp]
         L.yalps_ctx_destroy.restype = None
         L.yalps_ctx_destroy.argtypes = [vp]
         L.yalps_tableau_create.restype = C.c_int32
@@ -218,6 +230,51 @@ class DeviceTableau:
     def close(self):
         if self.handle:
             lib().yalps_tableau_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+
+class NodeBatch:
+    """Batched branch-and-cut node evaluation: the root's optimal tableau stays in HBM, every node
+    (= a list of cuts (sign, variable, value)) gets its own workgroup (yalps_batch_*)."""
+
+    def __init__(self, ctx, width, root_height, max_cuts, max_nodes):
+        self.ctx, self.width, self.root_height = ctx, width, root_height
+        self.max_cuts, self.max_nodes = max_cuts, max_nodes
+        self.handle = C.c_void_p()
+        check(lib().yalps_batch_create(ctx.handle, width, root_height, max_cuts, max_nodes, C.byref(self.handle)))
+
+    def set_root(self, matrix, pos, var):
+        check(lib().yalps_batch_set_root(self.handle, _ptr(matrix, np.float64), _ptr(pos, np.int32), _ptr(var, np.int32)))
+
+    def solve(self, cut_lists, precision=1e-8, max_pivots=8192.0):
+        """cut_lists: per node a sequence of (sign, variable, value).  Returns (status names,
+        results, pivot counts, node heights, gpu_ms)."""
+        count = len(cut_lists)
+        off = np.zeros(count + 1, np.int32)
+        off[1:] = np.cumsum([len(c) for c in cut_lists])
+        flat = [c for cuts in cut_lists for c in cuts]
+        sign = np.array([c[0] for c in flat] or [0], np.int32)
+        var = np.array([c[1] for c in flat] or [0], np.int32)
+        val = np.array([c[2] for c in flat] or [0.0], np.float64)
+        st, res, piv, ms = np.empty(count, np.int32), np.empty(count, np.float64), np.empty(count, np.int64), C.c_float()
+        check(lib().yalps_batch_solve(self.handle, count, off.ctypes.data, sign.ctypes.data, var.ctypes.data,
+                                      val.ctypes.data, precision, float(max_pivots), st.ctypes.data, res.ctypes.data,
+                                      piv.ctypes.data, C.byref(ms)))
+        heights = self.root_height + np.diff(off)
+        return [STATUS[k] for k in st], res, piv, heights, ms.value
+
+    def download(self, node, height, matrix=False):
+        w = self.width
+        m = np.empty(height * w, np.float64) if matrix else None
+        col0 = np.empty(height, np.float64)
+        pos, var = np.empty(w + height, np.int32), np.empty(w + height, np.int32)
+        check(lib().yalps_batch_download(self.handle, node, height, _ptr(m, np.float64), col0.ctypes.data,
+                                         pos.ctypes.data, var.ctypes.data))
+        return m, col0, pos, var
+
+    def close(self):
+        if self.handle:
+            lib().yalps_batch_destroy(self.handle)
             self.handle = C.c_void_p()
 
 

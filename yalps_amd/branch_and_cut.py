@@ -62,7 +62,7 @@ def most_fractional_var(tableau, int_vars):
         row = int(tableau.position_of_variable[int_var]) - tableau.width
         if row < 0:
             continue
-        val = float(tableau.matrix[row * tableau.width])
+        val = tableau.rhs(row)
         frac = abs(val - _js_round(val))
         if frac > highest:
             highest, variable, value = frac, int_var, val
@@ -128,6 +128,96 @@ def branch_and_cut(simplex, tabmod, init_result, options):
                 heapq.heappush(branches, _Branch(result, cuts_lower))
         timedout = now() >= stop_time
         it += 1
+
+    unfinished = (timedout or it >= max_iterations) and bool(branches) and best_eval >= optimal_threshold
+    status = "timedout" if unfinished else ("infeasible" if not solution_found else "optimal")
+    return (TableauModel(best_tableau, sign, tabmod.variables, integers), status,
+            best_eval if solution_found else math.nan)
+
+
+def branch_and_cut_batched(tabmod, init_result, options, node_batch, stats=None):
+    """branchAndCut (:89-176) with the node LPs evaluated on the GPU in batches (yalps_batch_*):
+    whenever the popped node has no result yet, it and the next-best `node_batch - 1` frontier nodes
+    are solved together (one workgroup per node, root resident, cuts applied on the device).  A
+    node's LP depends only on the root and its cuts, so evaluating it early changes nothing; nodes
+    are consumed in exactly the reference's pop order.  Returns what branch_and_cut returns."""
+    from . import _native
+    tableau, sign, integers = tabmod.tableau, tabmod.sign, tabmod.integers
+    precision, max_iterations = options["precision"], options["maxIterations"]
+    tolerance, timeout = options["tolerance"], options["timeout"]
+    init_variable, init_value, init_frac = most_fractional_var(tableau, integers)
+    if init_frac <= precision:
+        return tabmod, "optimal", init_result
+
+    branches = []
+    heapq.heappush(branches, _Branch(init_result, ((-1, init_variable, float(math.ceil(init_value))),)))
+    heapq.heappush(branches, _Branch(init_result, ((1, init_variable, float(math.floor(init_value))),)))
+
+    max_extra_rows = len(integers) * 2
+    ctx = _native.Context(0)
+    batch = _native.NodeBatch(ctx, tableau.width, tableau.height, max_extra_rows, node_batch)
+    batch.set_root(tableau.matrix, tableau.position_of_variable, tableau.variable_at_position)
+    cache = {}
+    if stats is not None:
+        stats.update(batches=0, nodes_evaluated=0, nodes_used=0, pivots=0, gpu_ms=0.0)
+
+    def evaluate(first):
+        todo, seen = [first], {first}
+        for br in heapq.nsmallest(node_batch - 1, branches):
+            if br.cuts not in cache and br.cuts not in seen:
+                todo.append(br.cuts)
+                seen.add(br.cuts)
+        st, res, piv, heights, ms = batch.solve(todo, precision, options["maxPivots"])
+        for i, cuts in enumerate(todo):
+            view = None
+            if st[i] == "optimal":
+                _, col0, pos, var = batch.download(i, int(heights[i]))
+                view = Tableau(None, tableau.width, int(heights[i]), pos, var, col0)
+            cache[cuts] = (st[i], float(res[i]), view)
+        if stats is not None:
+            stats["batches"] += 1
+            stats["nodes_evaluated"] += len(todo)
+            stats["pivots"] += int(piv.sum())
+            stats["gpu_ms"] += ms
+
+    optimal_threshold = init_result * (1.0 - sign * tolerance)
+    now = lambda: time.time() * 1000.0  # noqa: E731
+    stop_time = timeout + now()
+    timedout = now() >= stop_time
+    solution_found, best_eval, best_tableau, it = False, math.inf, tableau, 0
+    try:
+        while it < max_iterations and branches and best_eval >= optimal_threshold and not timedout:
+            br = heapq.heappop(branches)
+            relaxed_eval, cuts = br.eval, br.cuts
+            if relaxed_eval > best_eval:
+                break
+            if cuts not in cache:
+                evaluate(cuts)
+            status, result, current = cache.pop(cuts)
+            if stats is not None:
+                stats["nodes_used"] += 1
+            if status == "optimal" and result < best_eval:
+                variable, value, frac = most_fractional_var(current, integers)
+                if frac <= precision:
+                    solution_found, best_eval, best_tableau = True, result, current
+                else:
+                    cuts_upper, cuts_lower = [], []
+                    for cut in cuts:
+                        direction, v = cut[0], cut[1]
+                        if v == variable:
+                            (cuts_lower if direction < 0 else cuts_upper).append(cut)
+                        else:
+                            cuts_upper.append(cut)
+                            cuts_lower.append(cut)
+                    cuts_lower.append((1, variable, float(math.floor(value))))
+                    cuts_upper.append((-1, variable, float(math.ceil(value))))
+                    heapq.heappush(branches, _Branch(result, tuple(cuts_upper)))
+                    heapq.heappush(branches, _Branch(result, tuple(cuts_lower)))
+            timedout = now() >= stop_time
+            it += 1
+    finally:
+        batch.close()
+        ctx.close()
 
     unfinished = (timedout or it >= max_iterations) and bool(branches) and best_eval >= optimal_threshold
     status = "timedout" if unfinished else ("infeasible" if not solution_found else "optimal")

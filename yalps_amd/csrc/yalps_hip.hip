@@ -1304,6 +1304,231 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// batch_kernel: many independent branch-and-cut nodes at once, ONE workgroup per node
+// (BASELINE config 4).  A node's LP is the root's optimal tableau plus one
+// row per cut (src/branchAndCut.ts:22-61 `applyCuts`), re-solved with simplex() (:127).  The
+// root stays resident in HBM; every workgroup builds its node's tableau in its own workspace and
+// runs the whole two-phase loop there with workgroup-local synchronisation only -- nodes are
+// independent, there is no cross-workgroup communication and no host round trip.
+// Per pivot: the pivot column is gathered into LDS first (so rows can then be updated in place),
+// the pivot row is normalised into LDS (FLUSHED marks entries pivot() zeroed), the sweep gives
+// every lane fixed 16-byte column units and walks the rows.
+// ------------------------------------------------------------------------------------------
+constexpr unsigned long long FLUSHED = 0x7FF8C0DEC0DE5EEDull; // quiet NaN payload no arithmetic produces
+
+struct BatchDesc {
+    const double *root_mat, *root_rhs; // [h0][pitch], [h0]
+    const int32_t *root_pos, *root_var; // [w + h0]
+    double *ws_mat, *ws_rhs;           // per node: [hmax][pitch], [hmax]
+    int32_t *ws_pos, *ws_var;          // per node: [permmax]
+    const int32_t *cut_off, *cut_sign, *cut_var; // cuts of node i: [cut_off[i], cut_off[i+1])
+    const double *cut_val;
+    int32_t *status, *height;
+    double *result;
+    long long *pivots;
+    int32_t w, n, pitch, h0, hmax, permmax;
+    double precision, max_pivots;
+};
+
+template <int T>
+__global__ __launch_bounds__(T) void batch_kernel(BatchDesc d) {
+    __shared__ double sk[2][16];
+    __shared__ int si[2][16];
+    extern __shared__ double sh_dyn[]; // colbuf[hmax], prow[pitch]
+    double *colbuf = sh_dyn, *prow = sh_dyn + d.hmax;
+
+    const int tid = threadIdx.x, node = blockIdx.x;
+    const int w = d.w, n = d.n, pitch = d.pitch, h0 = d.h0;
+    const double precision = d.precision, max_pivots = d.max_pivots;
+    double *mat = d.ws_mat + (size_t)node * d.hmax * pitch;
+    double *rhs = d.ws_rhs + (size_t)node * d.hmax;
+    int32_t *pos = d.ws_pos + (size_t)node * d.permmax;
+    int32_t *var = d.ws_var + (size_t)node * d.permmax;
+    const int c_lo = d.cut_off[node], ncuts = d.cut_off[node + 1] - c_lo;
+    const int h = h0 + ncuts;
+    const int units = pitch / 2;
+    int slot = 0;
+
+    // ---- applyCuts (src/branchAndCut.ts:22-61) ----
+    for (int r = 0; r < h0; r++) {
+        const double *src = d.root_mat + (size_t)r * pitch;
+        double *dst = mat + (size_t)r * pitch;
+        for (int u = tid; u < units; u += T)
+            *reinterpret_cast<double2 *>(dst + 2 * u) = *reinterpret_cast<const double2 *>(src + 2 * u);
+    }
+    for (int r = tid; r < h0; r += T) rhs[r] = d.root_rhs[r];
+    for (int i = 0; i < ncuts; i++) {
+        const double sign = (double)d.cut_sign[c_lo + i], value = d.cut_val[c_lo + i];
+        const int p = d.root_pos[d.cut_var[c_lo + i]];
+        double *dst = mat + (size_t)(h0 + i) * pitch;
+        if (p < w) { // non-basic at the root: sign * x <= sign * value   (:32-35)
+            for (int c = tid; c < pitch; c += T) dst[c] = (c == p - 1) ? sign : 0.0;
+            if (tid == 0) rhs[h0 + i] = sign * value;
+        } else { // basic in root row p - w: substitute that row   (:36-42)
+            const double *src = d.root_mat + (size_t)(p - w) * pitch;
+            for (int c = tid; c < pitch; c += T) dst[c] = c < n ? -sign * src[c] : 0.0;
+            if (tid == 0) rhs[h0 + i] = sign * (value - d.root_rhs[p - w]);
+        }
+    }
+    for (int i = tid; i < w + h; i += T) { // :46-52
+        pos[i] = i < w + h0 ? d.root_pos[i] : i;
+        var[i] = i < w + h0 ? d.root_var[i] : i;
+    }
+    __syncthreads();
+
+    // ---- simplex(): src/simplex.ts:106-142 then :66-103 ----
+    int phase = 1, status = YALPS_CYCLED;
+    double iter = 0.0, result = NAN;
+    long long pivots = 0;
+    for (;;) {
+        if (!(iter < max_pivots)) break; // "cycled"
+        int row = 0, col = 0;
+        if (phase == 1) {
+            KI c = {INFINITY, INT_MAX};
+            for (int r = 1 + tid; r < h; r += T) {
+                const double v = rhs[r];
+                if (v < -precision && ki_better(v, r, c.k, c.i)) {
+                    c.k = v;
+                    c.i = r;
+                }
+            }
+            c = block_argmin<T>(c, sk, si, slot);
+            slot ^= 1;
+            if (c.i == INT_MAX) {
+                phase = 2;
+                iter = 0.0;
+                continue;
+            }
+            row = c.i;
+            const double *mrow = mat + (size_t)row * pitch;
+            KI e = {INFINITY, INT_MAX};
+            for (int cc = tid; cc < n; cc += T) {
+                const double coefficient = mrow[cc];
+                if (coefficient < -precision) {
+                    const double ratio = -mat[cc] / coefficient;
+                    if (ratio > -INFINITY && ki_better(-ratio, cc + 1, e.k, e.i)) {
+                        e.k = -ratio;
+                        e.i = cc + 1;
+                    }
+                }
+            }
+            e = block_argmin<T>(e, sk, si, slot);
+            slot ^= 1;
+            if (e.i == INT_MAX) {
+                status = YALPS_INFEASIBLE;
+                break;
+            }
+            col = e.i;
+        } else {
+            KI pr = {INFINITY, INT_MAX};
+            for (int cc = tid; cc < n; cc += T) {
+                const double rc = mat[cc];
+                if (rc > precision && ki_better(-rc, cc + 1, pr.k, pr.i)) {
+                    pr.k = -rc;
+                    pr.i = cc + 1;
+                }
+            }
+            pr = block_argmin<T>(pr, sk, si, slot);
+            slot ^= 1;
+            if (pr.i == INT_MAX) {
+                status = YALPS_OPTIMAL;
+                result = round_to_precision(rhs[0], precision);
+                break;
+            }
+            col = pr.i;
+            KI c = {INFINITY, INT_MAX};
+            for (int r = 1 + tid; r < h; r += T) {
+                const double value = mat[(size_t)r * pitch + col - 1];
+                if (value <= precision) continue;
+                const double ratio = rhs[r] / value;
+                if (!(ratio < INFINITY)) continue;
+                const double key = (ratio <= precision) ? -INFINITY : ratio;
+                if (ki_better(key, r, c.k, c.i)) {
+                    c.k = key;
+                    c.i = r;
+                }
+            }
+            c = block_argmin<T>(c, sk, si, slot);
+            slot ^= 1;
+            if (c.i == INT_MAX) {
+                status = YALPS_UNBOUNDED;
+                result = (double)col;
+                break;
+            }
+            row = c.i;
+        }
+        // ---- pivot(row, col): src/simplex.ts:5-39 ----
+        for (int r = tid; r < h; r += T) colbuf[r] = mat[(size_t)r * pitch + col - 1];
+        __syncthreads();
+        const double q = colbuf[row], rhs_row = rhs[row];
+        double *mrow = mat + (size_t)row * pitch;
+        for (int c = tid; c < pitch; c += T) {
+            const double v = mrow[c];
+            const bool nz = fabs(v) > 1e-16;
+            const double pn = nz ? v / q : 0.0;
+            mrow[c] = (c == col - 1) ? 1.0 / q : pn;
+            prow[c] = nz ? pn : __longlong_as_double((long long)FLUSHED);
+        }
+        __syncthreads(); // (also: everybody has read rhs[row] before it changes)
+        const bool nz_rhs = fabs(rhs_row) > 1e-16;
+        const double pn_rhs = nz_rhs ? rhs_row / q : 0.0;
+        for (int r = tid; r < h; r += T) {
+            if (r == row) {
+                rhs[r] = pn_rhs;
+            } else if (nz_rhs && fabs(colbuf[r]) > 1e-16) {
+                const double prod = colbuf[r] * pn_rhs;
+                rhs[r] = rhs[r] - prod;
+            }
+        }
+        for (int u = tid; u < units; u += T) {
+            const double2 p = *reinterpret_cast<const double2 *>(prow + 2 * u);
+            const bool f0 = (unsigned long long)__double_as_longlong(p.x) != FLUSHED;
+            const bool f1 = (unsigned long long)__double_as_longlong(p.y) != FLUSHED;
+            const bool has_col = (col - 1) >> 1 == u;
+#pragma unroll 4
+            for (int r = 0; r < h; r++) {
+                const double coef = colbuf[r];
+                if (r == row || !(fabs(coef) > 1e-16)) continue; // uniform
+                double2 *xp = reinterpret_cast<double2 *>(mat + (size_t)r * pitch + 2 * u);
+                double2 x = *xp;
+                if (f0) {
+                    const double prod = coef * p.x;
+                    x.x = x.x - prod;
+                }
+                if (f1) {
+                    const double prod = coef * p.y;
+                    x.y = x.y - prod;
+                }
+                if (has_col) {
+                    const double nq = -coef / q;
+                    if ((col - 1) & 1)
+                        x.y = nq;
+                    else
+                        x.x = nq;
+                }
+                *xp = x;
+            }
+        }
+        if (tid == 0) { // :7-12
+            const int leaving = var[w + row], entering = var[col];
+            var[w + row] = entering;
+            var[col] = leaving;
+            pos[leaving] = col;
+            pos[entering] = w + row;
+        }
+        iter += 1.0;
+        pivots += 1;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        d.status[node] = status;
+        d.result[node] = result;
+        d.pivots[node] = pivots;
+        d.height[node] = h;
+    }
+}
+
 // Applies a pending basis swap left by the last APPLY launch (single-pivot API).
 __global__ void flush_swap_kernel(Desc d, int parity) {
     YState *S = d.st + parity;
@@ -2018,6 +2243,152 @@ int32_t yalps_shard_poll(yalps_tableau *t, int32_t *status_out, double *result_o
     if (status_out) *status_out = now.status;
     if (result_out) *result_out = now.result;
     if (pivots_out) *pivots_out = now.pivots;
+    return 0;
+}
+
+// ---- batched branch-and-cut node evaluation (BASELINE config 4) ---------------------------------
+struct yalps_batch {
+    yalps_ctx *ctx = nullptr;
+    BatchDesc d{};
+    int32_t max_nodes = 0, max_cuts = 0;
+    double *root_mat = nullptr, *root_rhs = nullptr;
+    int32_t *root_pos = nullptr, *root_var = nullptr;
+    int32_t *cut_off = nullptr, *cut_sign = nullptr, *cut_var = nullptr;
+    double *cut_val = nullptr;
+    size_t shmem = 0;
+    int32_t last_count = 0;
+};
+
+int32_t yalps_batch_create(yalps_ctx *ctx, int32_t width, int32_t root_height, int32_t max_cuts, int32_t max_nodes,
+                           yalps_batch **out) {
+    if (!ctx || !out || width < 2 || root_height < 1 || max_cuts < 1 || max_nodes < 1)
+        return fail(YALPS_E_ARG, "yalps_batch_create: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    yalps_batch *b = new yalps_batch();
+    b->ctx = ctx;
+    b->max_nodes = max_nodes;
+    b->max_cuts = max_cuts;
+    BatchDesc &d = b->d;
+    d.w = width;
+    d.n = width - 1;
+    d.pitch = (d.n + 15) / 16 * 16;
+    d.h0 = root_height;
+    d.hmax = root_height + max_cuts;
+    d.permmax = width + d.hmax;
+    b->shmem = sizeof(double) * ((size_t)d.hmax + d.pitch);
+    if (b->shmem > 150 * 1024) return fail(YALPS_E_ARG, "yalps_batch_create: node tableau too large for the batched path");
+    const size_t nm = (size_t)max_nodes;
+    HIP_TRY(hipMalloc(&b->root_mat, sizeof(double) * (size_t)d.h0 * d.pitch));
+    HIP_TRY(hipMemset(b->root_mat, 0, sizeof(double) * (size_t)d.h0 * d.pitch));
+    HIP_TRY(hipMalloc(&b->root_rhs, sizeof(double) * (size_t)d.h0));
+    HIP_TRY(hipMalloc(&b->root_pos, sizeof(int32_t) * (size_t)(width + d.h0)));
+    HIP_TRY(hipMalloc(&b->root_var, sizeof(int32_t) * (size_t)(width + d.h0)));
+    HIP_TRY(hipMalloc(&d.ws_mat, sizeof(double) * nm * d.hmax * d.pitch));
+    HIP_TRY(hipMalloc(&d.ws_rhs, sizeof(double) * nm * d.hmax));
+    HIP_TRY(hipMalloc(&d.ws_pos, sizeof(int32_t) * nm * d.permmax));
+    HIP_TRY(hipMalloc(&d.ws_var, sizeof(int32_t) * nm * d.permmax));
+    HIP_TRY(hipMalloc(&b->cut_off, sizeof(int32_t) * (nm + 1)));
+    HIP_TRY(hipMalloc(&b->cut_sign, sizeof(int32_t) * nm * max_cuts));
+    HIP_TRY(hipMalloc(&b->cut_var, sizeof(int32_t) * nm * max_cuts));
+    HIP_TRY(hipMalloc(&b->cut_val, sizeof(double) * nm * max_cuts));
+    HIP_TRY(hipMalloc(&d.status, sizeof(int32_t) * nm));
+    HIP_TRY(hipMalloc(&d.height, sizeof(int32_t) * nm));
+    HIP_TRY(hipMalloc(&d.result, sizeof(double) * nm));
+    HIP_TRY(hipMalloc(&d.pivots, sizeof(long long) * nm));
+    d.root_mat = b->root_mat;
+    d.root_rhs = b->root_rhs;
+    d.root_pos = b->root_pos;
+    d.root_var = b->root_var;
+    d.cut_off = b->cut_off;
+    d.cut_sign = b->cut_sign;
+    d.cut_var = b->cut_var;
+    d.cut_val = b->cut_val;
+    if (b->shmem > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(batch_kernel<256>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->shmem));
+    *out = b;
+    return 0;
+}
+
+void yalps_batch_destroy(yalps_batch *b) {
+    if (!b) return;
+    (void)hipSetDevice(b->ctx->device);
+    (void)hipStreamSynchronize(b->ctx->stream);
+    void *bufs[] = {b->root_mat, b->root_rhs, b->root_pos, b->root_var, b->d.ws_mat, b->d.ws_rhs, b->d.ws_pos, b->d.ws_var,
+                    b->cut_off, b->cut_sign, b->cut_var, b->cut_val, b->d.status, b->d.height, b->d.result, b->d.pivots};
+    for (void *p : bufs)
+        if (p) (void)hipFree(p);
+    delete b;
+}
+
+int32_t yalps_batch_set_root(yalps_batch *b, const double *matrix, const int32_t *pos, const int32_t *var) {
+    if (!b || !matrix || !pos || !var) return fail(YALPS_E_ARG, "yalps_batch_set_root: NULL argument");
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    hipStream_t s = b->ctx->stream;
+    const BatchDesc &d = b->d;
+    HIP_TRY(hipMemcpy2DAsync(b->root_rhs, sizeof(double), matrix, sizeof(double) * d.w, sizeof(double), d.h0,
+                             hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpy2DAsync(b->root_mat, sizeof(double) * d.pitch, matrix + 1, sizeof(double) * d.w,
+                             sizeof(double) * d.n, d.h0, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(b->root_pos, pos, sizeof(int32_t) * (size_t)(d.w + d.h0), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(b->root_var, var, sizeof(int32_t) * (size_t)(d.w + d.h0), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+int32_t yalps_batch_solve(yalps_batch *b, int32_t count, const int32_t *cut_offsets, const int32_t *cut_sign,
+                          const int32_t *cut_var, const double *cut_value, double precision, double maxPivots,
+                          int32_t *status_out, double *result_out, int64_t *pivots_out, float *gpu_ms_out) {
+    if (!b || count < 1 || count > b->max_nodes || !cut_offsets || !cut_sign || !cut_var || !cut_value)
+        return fail(YALPS_E_ARG, "yalps_batch_solve: bad argument");
+    const int32_t total = cut_offsets[count];
+    for (int32_t i = 0; i < count; i++)
+        if (cut_offsets[i + 1] - cut_offsets[i] > b->max_cuts || cut_offsets[i + 1] < cut_offsets[i])
+            return fail(YALPS_E_ARG, "yalps_batch_solve: a node has more cuts than the batch was created for");
+    yalps_ctx *c = b->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpyAsync(b->cut_off, cut_offsets, sizeof(int32_t) * (size_t)(count + 1), hipMemcpyHostToDevice, s));
+    if (total > 0) {
+        HIP_TRY(hipMemcpyAsync(b->cut_sign, cut_sign, sizeof(int32_t) * (size_t)total, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(b->cut_var, cut_var, sizeof(int32_t) * (size_t)total, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(b->cut_val, cut_value, sizeof(double) * (size_t)total, hipMemcpyHostToDevice, s));
+    }
+    b->d.precision = precision;
+    b->d.max_pivots = maxPivots;
+    HIP_TRY(hipEventRecord(c->ev0, s));
+    batch_kernel<256><<<dim3(count), dim3(256), b->shmem, s>>>(b->d);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev1, s));
+    if (status_out) HIP_TRY(hipMemcpyAsync(status_out, b->d.status, sizeof(int32_t) * (size_t)count, hipMemcpyDeviceToHost, s));
+    if (result_out) HIP_TRY(hipMemcpyAsync(result_out, b->d.result, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, s));
+    if (pivots_out) HIP_TRY(hipMemcpyAsync(pivots_out, b->d.pivots, sizeof(int64_t) * (size_t)count, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (gpu_ms_out) HIP_TRY(hipEventElapsedTime(gpu_ms_out, c->ev0, c->ev1));
+    b->last_count = count;
+    return 0;
+}
+
+int32_t yalps_batch_download(yalps_batch *b, int32_t node, int32_t height, double *matrix, double *col0,
+                             int32_t *pos, int32_t *var) {
+    if (!b || node < 0 || node >= b->last_count || height < 1 || height > b->d.hmax)
+        return fail(YALPS_E_ARG, "yalps_batch_download: bad argument");
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    hipStream_t s = b->ctx->stream;
+    const BatchDesc &d = b->d;
+    const double *mat = d.ws_mat + (size_t)node * d.hmax * d.pitch;
+    const double *rhs = d.ws_rhs + (size_t)node * d.hmax;
+    if (matrix) {
+        HIP_TRY(hipMemcpy2DAsync(matrix, sizeof(double) * d.w, rhs, sizeof(double), sizeof(double), height,
+                                 hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpy2DAsync(matrix + 1, sizeof(double) * d.w, mat, sizeof(double) * d.pitch, sizeof(double) * d.n,
+                                 height, hipMemcpyDeviceToHost, s));
+    }
+    if (col0) HIP_TRY(hipMemcpyAsync(col0, rhs, sizeof(double) * (size_t)height, hipMemcpyDeviceToHost, s));
+    const size_t nperm = sizeof(int32_t) * (size_t)(d.w + height);
+    if (pos) HIP_TRY(hipMemcpyAsync(pos, d.ws_pos + (size_t)node * d.permmax, nperm, hipMemcpyDeviceToHost, s));
+    if (var) HIP_TRY(hipMemcpyAsync(var, d.ws_var + (size_t)node * d.permmax, nperm, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
     return 0;
 }
 

@@ -24,6 +24,11 @@ class Tableau:
     height: int
     position_of_variable: np.ndarray
     variable_at_position: np.ndarray
+    col0: np.ndarray = None  # RHS column alone, when only that was copied back from the GPU (matrix may be None)
+
+    def rhs(self, row):
+        """index(tableau, row, 0)"""
+        return float(self.col0[row]) if self.col0 is not None else float(self.matrix[row * self.width])
 
 
 @dataclass

@@ -59,7 +59,7 @@ def solution(tabmod, status, result, options):
         variables = []
         for i, (key, _) in enumerate(vars_):
             row = int(tableau.position_of_variable[i + 1]) - tableau.width
-            value = float(tableau.matrix[row * tableau.width]) if row >= 0 else 0.0
+            value = tableau.rhs(row) if row >= 0 else 0.0
             if value > precision:
                 variables.append((key, round_to_precision(value, precision)))
             elif options["includeZeroVariables"]:
@@ -72,7 +72,7 @@ def solution(tabmod, status, result, options):
     return {"status": status, "result": math.nan, "variables": []}  # infeasible | cycled | timedout w/o result
 
 
-def _solve_with(simplex, model, options=None):
+def _solve_with(simplex, model, options=None, node_batch=0, stats=None):
     """src/YALPS.ts:73-92 with the simplex backend as a parameter (tests drive the host logic
     with the CPU oracle through this; the product binds the HIP backend below)."""
     tabmod = tableau_model(model)
@@ -82,11 +82,19 @@ def _solve_with(simplex, model, options=None):
     status, result = simplex(tabmod.tableau, opt)
     if not tabmod.integers or status != "optimal":
         return solution(tabmod, status, result, opt)
-    int_tabmod, int_status, int_result = branch_and_cut(simplex, tabmod, result, opt)
+    if node_batch > 1 and not opt["checkCycles"]:
+        from .branch_and_cut import branch_and_cut_batched
+        int_tabmod, int_status, int_result = branch_and_cut_batched(tabmod, result, opt, node_batch, stats)
+    else:
+        int_tabmod, int_status, int_result = branch_and_cut(simplex, tabmod, result, opt)
     return solution(int_tabmod, int_status, int_result, opt)
 
 
-def solve(model, options=None):
+def solve(model, options=None, node_batch=0, stats=None):
     """Runs the solver on `model` (see yalps_amd.model) with `options` (keys as in the reference's
-    `Options`, src/types.ts:203-265).  Returns {"status", "result", "variables": [(key, value)]}."""
-    return _solve_with(hip_simplex, model, options)
+    `Options`, src/types.ts:203-265).  Returns {"status", "result", "variables": [(key, value)]}.
+
+    node_batch > 1: branch and cut evaluates that many frontier nodes per GPU batch (speculatively,
+    best first; results are committed in the reference's pop order, so the outcome is the same as
+    node_batch = 0, which re-solves one node at a time through the drop-in simplex call)."""
+    return _solve_with(hip_simplex, model, options, node_batch, stats)
