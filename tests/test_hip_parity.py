@@ -4,7 +4,11 @@ inputs.  Bit-exact: status, result, pivot count, permutations, RHS column, whole
 import numpy as np
 import pytest
 
+import os
+
 from tests import _golden as G
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -153,3 +157,48 @@ def test_solve_readme_example(nat):
                            "dresser": {"wood": 20, "labor": 10, "profit": 1600, "storage": 50}},
              "integers": ["table", "dresser"]}
     assert S.solve(model) == {"status": "optimal", "result": 14400.0, "variables": [("table", 8.0), ("dresser", 3.0)]}
+
+
+def test_resident_fallback_resumes_with_streaming_kernel(oracle, tmp_path):
+    """If the resident kernel ever reports a failed hand-off, the solve continues with the
+    streaming kernel from the last consistent state.  Forced here after two chunks of 40 pivots
+    (in a child process: the switches are read when the context is created)."""
+    import subprocess
+    import sys
+    rec = next(r for r in G.records("dense") if r["M"] == 256)
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "from tests import _golden as G, _oracle\n"
+        "from yalps_amd import _native as n\n"
+        "rec = next(r for r in G.records('dense') if r['M'] == 256)\n"
+        "m = G.initial_matrix(rec, _oracle.load(), dense_gen=n.dense_lp); pos, var = G.identity_perms(rec)\n"
+        "ctx = n.Context(0); t = n.DeviceTableau(ctx, rec['width'], rec['height']); t.upload(m, rec['height'], pos, var)\n"
+        "st, res, piv, _ = t.solve(max_pivots=float('inf')); info = t.info(); gm, gp, gv = t.download()\n"
+        "exp = G.expected(rec)\n"
+        "assert info['last_path'] == 'resident+streaming', info\n"
+        "assert (st, res, piv) == (exp['status'], exp['result'], exp['n_pivots']), (st, res, piv)\n"
+        "assert G.sha256(gm) == exp['final_sha256'] and np.array_equal(gp, exp['pos']) and np.array_equal(gv, exp['var'])\n"
+        "print('ok')\n" % ROOT)
+    env = dict(__import__("os").environ, YALPS_HIP_RESIDENT_CHUNK="40", YALPS_HIP_RESIDENT_FAULT="2")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_resident_chunking_and_repeatability(nat, ctx, oracle):
+    """Several resident launches per solve (state carried across launches) and 10 repeated solves
+    of the 1025 x 1025 case: every run must reproduce the reference bit for bit."""
+    rec = next(r for r in G.records("dense") if r["M"] == 1024)
+    exp = G.expected(rec)
+    m0 = G.initial_matrix(rec, oracle, dense_gen=nat.dense_lp)
+    pos0, var0 = G.identity_perms(rec)
+    t = nat.DeviceTableau(ctx, rec["width"], rec["height"])
+    try:
+        for _ in range(10):
+            t.upload(m0, rec["height"], pos0, var0)
+            st, res, piv, _ = t.solve(max_pivots=float("inf"))
+            assert (st, res, piv) == (exp["status"], exp["result"], exp["n_pivots"])
+            gm, gp, gv = t.download()
+            assert G.sha256(gm) == exp["final_sha256"] and np.array_equal(gp, exp["pos"])
+        assert t.info()["last_path"] == "resident"
+    finally:
+        t.close()

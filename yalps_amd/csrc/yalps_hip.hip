@@ -1606,6 +1606,8 @@ struct yalps_ctx {
     bool eager = false;
     bool nt_stores = false;
     bool resident = true; // use the on-chip resident kernel when the tableau fits (YALPS_HIP_RESIDENT=0: never)
+    int resident_chunk = RESIDENT_CHUNK; // pivots per resident launch (YALPS_HIP_RESIDENT_CHUNK)
+    int resident_fault = 0; // test hook: treat the N-th resident launch as failed (YALPS_HIP_RESIDENT_FAULT=N)
     int num_cus = 256;
     int max_blocks = 256; // workgroups per launch (one per CU by default)
 };
@@ -1620,6 +1622,8 @@ struct yalps_tableau {
     int last_path = 0;               // what the last solve ran: 1 resident, 2 streaming, 3 both
     int64_t last_launches = 0;       // kernel launches of the last solve that did work (resident: chunks)
     size_t rshmem = 0;
+    int32_t *perm_backup = nullptr; // basis before the resident launch in flight (restored if it fails)
+    int32_t perm_backup_len = 0;
     int32_t perm_len = 0; // entries of pos / var (width + GLOBAL height)
     Variant var{};
     int nb = 1;
@@ -1778,6 +1782,9 @@ static int32_t ctx_create(int32_t device, void *ext_stream, bool adopt, yalps_ct
     c->eager = env_int("YALPS_HIP_EAGER", 0) != 0;
     c->nt_stores = env_int("YALPS_HIP_NT", 1) != 0;
     c->resident = env_int("YALPS_HIP_RESIDENT", 1) != 0;
+    c->resident_chunk = env_int("YALPS_HIP_RESIDENT_CHUNK", RESIDENT_CHUNK);
+    if (c->resident_chunk < 1) c->resident_chunk = 1;
+    c->resident_fault = env_int("YALPS_HIP_RESIDENT_FAULT", 0);
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; // measured 1-2 % faster in the pivot loop at 2049^2 and 4097^2
     c->max_blocks = env_int("YALPS_HIP_BLOCKS", prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
     if (c->max_blocks < 1) c->max_blocks = 1;
@@ -1891,7 +1898,7 @@ void yalps_tableau_destroy(yalps_tableau *t) {
         if (t->graph[k]) (void)hipGraphDestroy(t->graph[k]);
     }
     Desc &d = t->d;
-    void *bufs[] = {d.mat[0], d.mat[1], d.rhs[0], d.rhs[1], d.pos, d.var, d.st, d.cst, d.rc_rows[0], d.rc_rows[1],
+    void *bufs[] = {d.mat[0], d.mat[1], d.rhs[0], d.rhs[1], d.pos, d.var, d.st, d.cst, d.rc_rows[0], d.rc_rows[1], t->perm_backup,
                     d.rc_key[0], d.rc_key[1], d.rc_flag[0], d.rc_flag[1], d.rc_err, d.part_ratio[0], d.part_ratio[1], d.part_rhs[0], d.part_rhs[1],
                     t->hist[0], t->hist[1]};
     for (void *p : bufs)
@@ -2023,17 +2030,29 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
             for (int k = 0; k < 2; k++)
                 HIP_TRY(hipMemsetAsync(t->d.rc_flag[k], 0, sizeof(unsigned long long) * 2 * (size_t)t->nb, s));
             HIP_TRY(hipMemsetAsync(t->d.rc_err, 0, sizeof(int32_t), s));
-            t->rvar.fn<<<dim3(t->nb), dim3(t->rvar.T), shmem, s>>>(t->d, parity, RESIDENT_CHUNK);
+            // the kernel rewrites the basis in place on exit: keep the old one until the launch is known good
+            if (t->perm_backup_len < 2 * t->perm_len) {
+                if (t->perm_backup) HIP_TRY(hipFree(t->perm_backup));
+                HIP_TRY(hipMalloc(&t->perm_backup, sizeof(int32_t) * 2 * (size_t)t->perm_len));
+                t->perm_backup_len = 2 * t->perm_len;
+            }
+            HIP_TRY(hipMemcpyAsync(t->perm_backup, t->d.var, sizeof(int32_t) * (size_t)t->perm_len, hipMemcpyDeviceToDevice, s));
+            HIP_TRY(hipMemcpyAsync(t->perm_backup + t->perm_len, t->d.pos, sizeof(int32_t) * (size_t)t->perm_len,
+                                   hipMemcpyDeviceToDevice, s));
+            t->rvar.fn<<<dim3(t->nb), dim3(t->rvar.T), shmem, s>>>(t->d, parity, c->resident_chunk);
             t->last_path |= 1;
             t->last_launches++;
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(herr, t->d.rc_err, sizeof(int32_t), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipMemcpyAsync(&t->host_state[1], t->d.st + (parity ^ 1), sizeof(YState), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
-            if (*herr) {
+            if (*herr || (c->resident_fault > 0 && t->last_launches == c->resident_fault)) {
                 // a workgroup gave up waiting (grid not co-resident?): never again on this context;
                 // carry on with the streaming kernel from the last consistent state (st[parity])
                 c->resident = false;
+                HIP_TRY(hipMemcpyAsync(t->d.var, t->perm_backup, sizeof(int32_t) * (size_t)t->perm_len, hipMemcpyDeviceToDevice, s));
+                HIP_TRY(hipMemcpyAsync(t->d.pos, t->perm_backup + t->perm_len, sizeof(int32_t) * (size_t)t->perm_len,
+                                       hipMemcpyDeviceToDevice, s));
                 YState last;
                 HIP_TRY(hipMemcpy(&last, t->d.st + parity, sizeof(YState), hipMemcpyDeviceToHost));
                 t->cur = last.mbuf;
