@@ -1256,7 +1256,8 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
             pos[leaving] = col;
             pos[entering] = w + row;
         }
-        __syncthreads(); // sh_val / sh_nq consumed before the next round rewrites them
+        // (no barrier here: the next write to sh_val / sh_nq comes after the gather's barrier, which every
+        // wave reaches only after it has finished reading them)
     }
 
     // ---------------- leave: tableau to the other buffer, state, basis ---------------------------
@@ -1866,6 +1867,8 @@ int32_t yalps_tableau_create(yalps_ctx *ctx, int32_t width, int32_t hcap, yalps_
     // workgroup in registers
     d.perm_len = t->perm_len;
     if (t->nb <= ctx->num_cus) {
+        // (16 waves per CU were tried for 2049^2: <1024,1,9> spills at the 128-VGPR cap and its barriers
+        // cost more: 92 K pivots/s against 144 K for <512,2,9>)
         const int rT = units <= 512 ? 256 : 512;
         const int rJ = units <= 256 ? 1 : units <= 1024 ? 2 : 4;
         for (const RVariant &v : kResident) {
