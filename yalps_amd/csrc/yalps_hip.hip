@@ -2161,6 +2161,7 @@ static int32_t ctx_create(int32_t device, void *ext_stream, bool adopt, yalps_ct
         return fail(YALPS_E_DEVICE, std::string("device is ") + prop.gcnArchName + ", this build targets gfx950 only");
     yalps_ctx *c = new yalps_ctx();
     c->device = device;
+    *out = c;
     if (adopt) {
         c->stream = static_cast<hipStream_t>(ext_stream); // e.g. torch's current stream (may be the null stream)
         c->own_stream = false;
@@ -2183,10 +2184,23 @@ static int32_t ctx_create(int32_t device, void *ext_stream, bool adopt, yalps_ct
     return 0;
 }
 
-int32_t yalps_ctx_create(int32_t device, yalps_ctx **out) { return ctx_create(device, nullptr, false, out); }
+static int32_t ctx_create_guarded(int32_t device, void *stream, bool adopt, yalps_ctx **out) {
+    if (!out) return fail(YALPS_E_ARG, "yalps_ctx_create: out is NULL");
+    *out = nullptr;
+    const int32_t rc = ctx_create(device, stream, adopt, out);
+    if (rc && *out) {
+        const std::string why = g_err;
+        yalps_ctx_destroy(*out);
+        *out = nullptr;
+        g_err = why;
+    }
+    return rc;
+}
+
+int32_t yalps_ctx_create(int32_t device, yalps_ctx **out) { return ctx_create_guarded(device, nullptr, false, out); }
 
 int32_t yalps_ctx_create_on_stream(int32_t device, void *hip_stream, yalps_ctx **out) {
-    return ctx_create(device, hip_stream, true, out);
+    return ctx_create_guarded(device, hip_stream, true, out);
 }
 
 void yalps_ctx_destroy(yalps_ctx *c) {
@@ -2198,8 +2212,7 @@ void yalps_ctx_destroy(yalps_ctx *c) {
     delete c;
 }
 
-int32_t yalps_tableau_create(yalps_ctx *ctx, int32_t width, int32_t hcap, yalps_tableau **out) {
-    if (!ctx || !out || width < 1 || hcap < 1) return fail(YALPS_E_ARG, "yalps_tableau_create: bad argument");
+static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, yalps_tableau **out) {
     if ((int64_t)width + hcap > INT32_MAX / 2) return fail(YALPS_E_ARG, "tableau too large");
     const int n = width - 1, units = (n + 1) / 2;
     // kernel variant: lanes x units-per-lane must span the row; rows in flight sized so that
@@ -2211,6 +2224,7 @@ int32_t yalps_tableau_create(yalps_ctx *ctx, int32_t width, int32_t hcap, yalps_
     HIP_TRY(hipSetDevice(ctx->device));
     yalps_tableau *t = new yalps_tableau();
     t->ctx = ctx;
+    *out = t; // reachable from now on: the wrapper frees a half-built object on failure
     const int forceR = env_int("YALPS_HIP_ROWS", 0);
     // spread the rows over all workgroups; rows in flight per lane R >= rows per workgroup if any
     // variant allows it (one batch per launch), else the largest R (several batches)
@@ -2288,6 +2302,19 @@ int32_t yalps_tableau_create(yalps_ctx *ctx, int32_t width, int32_t hcap, yalps_
     HIP_TRY(hipStreamSynchronize(s));
     *out = t;
     return 0;
+}
+
+int32_t yalps_tableau_create(yalps_ctx *ctx, int32_t width, int32_t hcap, yalps_tableau **out) {
+    if (!ctx || !out || width < 1 || hcap < 1) return fail(YALPS_E_ARG, "yalps_tableau_create: bad argument");
+    *out = nullptr;
+    const int32_t rc = tableau_create_impl(ctx, width, hcap, out);
+    if (rc && *out) {
+        const std::string why = g_err;
+        yalps_tableau_destroy(*out);
+        *out = nullptr;
+        g_err = why;
+    }
+    return rc;
 }
 
 void yalps_tableau_destroy(yalps_tableau *t) {
@@ -2679,13 +2706,12 @@ struct yalps_batch {
     int32_t last_count = 0;
 };
 
-int32_t yalps_batch_create(yalps_ctx *ctx, int32_t width, int32_t root_height, int32_t max_cuts, int32_t max_nodes,
-                           yalps_batch **out) {
-    if (!ctx || !out || width < 2 || root_height < 1 || max_cuts < 1 || max_nodes < 1)
-        return fail(YALPS_E_ARG, "yalps_batch_create: bad argument");
+static int32_t batch_create_impl(yalps_ctx *ctx, int32_t width, int32_t root_height, int32_t max_cuts, int32_t max_nodes,
+                                 yalps_batch **out) {
     HIP_TRY(hipSetDevice(ctx->device));
     yalps_batch *b = new yalps_batch();
     b->ctx = ctx;
+    *out = b;
     b->max_nodes = max_nodes;
     b->max_cuts = max_cuts;
     BatchDesc &d = b->d;
@@ -2728,6 +2754,21 @@ int32_t yalps_batch_create(yalps_ctx *ctx, int32_t width, int32_t root_height, i
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->shmem));
     *out = b;
     return 0;
+}
+
+int32_t yalps_batch_create(yalps_ctx *ctx, int32_t width, int32_t root_height, int32_t max_cuts, int32_t max_nodes,
+                           yalps_batch **out) {
+    if (!ctx || !out || width < 2 || root_height < 1 || max_cuts < 1 || max_nodes < 1)
+        return fail(YALPS_E_ARG, "yalps_batch_create: bad argument");
+    *out = nullptr;
+    const int32_t rc = batch_create_impl(ctx, width, root_height, max_cuts, max_nodes, out);
+    if (rc && *out) {
+        const std::string why = g_err;
+        yalps_batch_destroy(*out);
+        *out = nullptr;
+        g_err = why;
+    }
+    return rc;
 }
 
 void yalps_batch_destroy(yalps_batch *b) {
