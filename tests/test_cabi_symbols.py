@@ -42,7 +42,7 @@ def test_product_does_not_touch_the_oracle():
     """Nothing under yalps_amd/ may import, link or execute oracle/."""
     for dirpath, _, files in os.walk(os.path.join(ROOT, "yalps_amd")):
         for f in files:
-            if f.endswith((".py", ".hip", ".cc", ".h", ".js", ".mjs")):
+            if f.endswith((".py", ".hip", ".cuh", ".cc", ".h", ".js", ".mjs")):
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "liboracle" not in src and "simplex_oracle" not in src and "oracle/" not in src.replace(
                     "Nothing here imports the oracle", ""), os.path.join(dirpath, f)

@@ -1,0 +1,221 @@
+// common.cuh -- device-side state, descriptors, DPP arg-min reductions and small helpers shared by all kernels
+// Part of libyalps_hip.so; included by yalps_hip.hip inside its anonymous namespace (gfx950 only).
+#pragma once
+
+
+constexpr int RUNNING = -1;
+constexpr int MODE_FUSED = 0, MODE_DECIDE = 1, MODE_APPLY = 2, MODE_SHARD = 3;
+constexpr int SHARD_HDR = 8;  // doubles in front of the two candidate rows of a gather slot
+constexpr int MAX_SHARDS = 8; // one node of MI355X
+constexpr int LAUNCHES_PER_GRAPH = 64; // even: state parity returns to 0 after a replay
+constexpr int MAX_BLOCKS = 1024;       // partial arrays / reduction width
+// A quiet NaN with a payload no arithmetic produces: marks pivot-row entries that pivot() flushed to
+// zero (src/simplex.ts:18-23, i.e. columns NOT in `nonZeroColumns`) where the row is staged in LDS.
+constexpr unsigned long long FLUSHED = 0x7FF8C0DEC0DE5EEDull;
+
+// Per-solve constants (host-written once per solve; the cycle-history pointers again on growth).
+struct alignas(16) YConst {
+    int32_t height;
+    int32_t check_cycles;
+    int64_t hist_cap;
+    int32_t *hist_leaving, *hist_entering;
+    double precision, max_pivots;
+};
+
+// Dynamic solver state, ping-ponged between launches.  The hot path writes every field from
+// registers (no read-modify-write chain at the end of a launch).
+struct alignas(16) YState {
+    int32_t status;    // RUNNING or a YALPS_* status code
+    int32_t phase;     // 1 | 2
+    int32_t bootstrap; // no partials exist yet: next APPLY/FUSED launch only scans
+    int32_t la;        // column whose min-ratio partials are in part_ratio[pbuf] (0 = none priced)
+    int32_t pbuf;      // which partial buffers the next launch reads
+    int32_t mbuf;      // which tableau buffer holds the current tableau (the other one is written)
+    int32_t pause;     // cycle history full: host must grow it
+    int32_t dec_valid; // DECIDE -> APPLY hand-off
+    int32_t dec_row, dec_col;
+    // basis bookkeeping (src/simplex.ts:7-12) of the pivot just applied, carried out by the NEXT
+    // launch (its loads are then the oldest of that launch instead of the last of this one)
+    int32_t swap_valid, swap_row, swap_col;
+    int32_t pad_;
+    int64_t hist_len;
+    double iter; // pivots done in the current phase (src/simplex.ts:69,109)
+    double result;
+    int64_t pivots; // total over both phases
+};
+
+struct alignas(16) Part {
+    double key;
+    int32_t idx;
+    int32_t pad_;
+};
+
+struct Desc {
+    // The tableau is ping-ponged: a pivot reads buffer [mbuf] and writes buffer [mbuf ^ 1], so no
+    // workgroup ever reads a row (pivot row, objective row, pivot column) that another workgroup
+    // of the same launch is overwriting.
+    double *mat[2]; // [hcap][pitch]: columns 1..w-1 of the reference tableau
+    double *rhs[2]; // [hcap]: column 0
+    int32_t *pos, *var;
+    YState *st;          // [2], ping-pong by launch parity
+    YConst *cst;
+    Part *part_ratio[2]; // [MAX_BLOCKS] each
+    Part *part_rhs[2];
+    int32_t w, n, pitch, hcap; // n = w - 1 variable columns
+    int32_t nb;                // workgroups of an APPLY/FUSED launch = row stride = number of partials
+    // row sharding over GPUs: this rank holds the objective row (local row 0,
+    // replicated) + global rows [bounds[rank], bounds[rank+1]) as local rows 1..; a local row
+    // r >= 1 is global row r + row_base.  Unsharded: nshards = 1, row_base = 0.
+    int32_t nshards, shard_rank, row_base;
+    int32_t bounds[MAX_SHARDS + 1];
+    // resident (on-chip) solver: per-workgroup candidate hand-off buffers, ping-pong by epoch parity
+    double *rc_rows[2];             // [nb][pitch] candidate row of each workgroup
+    double *rc_key[2];              // [nb] RHS entry of each workgroup's candidate row
+    unsigned long long *rc_flag[2]; // [nb][2] {candidate key bits, (epoch << 32) | global row index}
+    int32_t *rc_err;                // set when a workgroup gives up waiting (never expected)
+    int32_t perm_len;
+};
+
+// ------------------------------------------------------------------------------------------
+// 64-lane arg-min with lowest-index tie-break (all four scans of the reference reduce to it).
+// Built on DPP lane permutes (VALU speed); __shfl_* would go through ds_bpermute, ~1 us per
+// 64-lane (double,int) reduction, which was most of a pivot's fixed cost.
+// ------------------------------------------------------------------------------------------
+struct KI {
+    double k;
+    int i;
+};
+
+__device__ __forceinline__ bool ki_better(double ka, int ia, double kb, int ib) {
+    return ka < kb || (ka == kb && ia < ib);
+}
+
+// DPP controls: quad_perm [1,0,3,2] / [2,3,0,1], row_half_mirror, row_mirror
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = dpp_i32<CTRL>(__double2loint(v)), hi = dpp_i32<CTRL>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+// every lane of a 16-lane row gets the row's minimum (keys are never NaN)
+__device__ __forceinline__ double row16_min(double v) {
+    v = fmin(v, dpp_f64<DPP_XOR1>(v));
+    v = fmin(v, dpp_f64<DPP_XOR2>(v));
+    v = fmin(v, dpp_f64<DPP_HALF_MIRROR>(v));
+    v = fmin(v, dpp_f64<DPP_MIRROR>(v));
+    return v;
+}
+__device__ __forceinline__ int row16_min(int v) {
+    v = min(v, dpp_i32<DPP_XOR1>(v));
+    v = min(v, dpp_i32<DPP_XOR2>(v));
+    v = min(v, dpp_i32<DPP_HALF_MIRROR>(v));
+    v = min(v, dpp_i32<DPP_MIRROR>(v));
+    return v;
+}
+__device__ __forceinline__ double lane_f64(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                            __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ KI row16_argmin(KI v) {
+    KI r;
+    r.k = row16_min(v.k);
+    r.i = row16_min(v.k == r.k ? v.i : INT_MAX);
+    return r;
+}
+// result uniform over the wave
+__device__ __forceinline__ KI wave_argmin(KI v) {
+    const double m = row16_min(v.k);
+    KI r;
+    r.k = fmin(fmin(lane_f64(m, 0), lane_f64(m, 16)), fmin(lane_f64(m, 32), lane_f64(m, 48)));
+    const int i = row16_min(v.k == r.k ? v.i : INT_MAX);
+    r.i = min(min(__builtin_amdgcn_readlane(i, 0), __builtin_amdgcn_readlane(i, 16)),
+              min(__builtin_amdgcn_readlane(i, 32), __builtin_amdgcn_readlane(i, 48)));
+    return r;
+}
+
+// Result broadcast to every lane of the workgroup.  sk / si: [2][16] LDS scratch, `slot`
+// alternates between consecutive calls (so one barrier per call is enough).
+template <int T>
+__device__ __forceinline__ KI block_argmin(KI v, double (*sk)[16], int (*si)[16], int slot) {
+    constexpr int NW = T / 64;
+    v = wave_argmin(v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) {
+        sk[slot][wv] = v.k;
+        si[slot][wv] = v.i;
+    }
+    __syncthreads();
+    KI r;
+    r.k = (lane & 15) < NW ? sk[slot][lane & 15] : INFINITY;
+    r.i = (lane & 15) < NW ? si[slot][lane & 15] : INT_MAX;
+    return row16_argmin(r); // every 16-lane row holds all NW wave results
+}
+
+// JS Math.round (halves toward +inf) and roundToPrecision (src/util.ts:1-4)
+__host__ __device__ inline double js_round(double x) {
+    if (!(fabs(x) < INFINITY)) return x; // NaN, +-inf
+    const double f = floor(x);
+    return (x - f >= 0.5) ? f + 1.0 : f;
+}
+__host__ __device__ inline double round_to_precision(double num, double precision) {
+    const double rounding = js_round(1.0 / precision);
+    return js_round((num + 2.220446049250313e-16) * rounding) / rounding;
+}
+
+// src/simplex.ts:44-63 -- every lane tests a set of candidate cycle lengths (DECIDE launches).
+__device__ __forceinline__ bool has_cycle(const YConst *C, int64_t hist_len, int leaving, int entering, int *flag) {
+    int32_t *hl = C->hist_leaving, *he = C->hist_entering;
+    const int64_t len = hist_len + 1;
+    if (threadIdx.x == 0) {
+        hl[len - 1] = leaving;
+        he[len - 1] = entering;
+        *flag = 0;
+    }
+    __syncthreads();
+    bool found = false;
+    for (int64_t length = 6 + threadIdx.x; length <= len / 2 && !found; length += blockDim.x) {
+        bool cycle = true;
+        for (int64_t i = 0; i < length; i++) {
+            const int64_t item = len - 1 - i;
+            if (hl[item] != hl[item - length] || he[item] != he[item - length]) {
+                cycle = false;
+                break;
+            }
+        }
+        found = cycle;
+    }
+    if (found) *flag = 1;
+    __syncthreads();
+    return *flag != 0;
+}
+
+// Sout = Sin, 16 bytes at a time, straight from global to global (a `YState s = *Sin` local copy
+// is turned into a per-lane LDS array by hipcc).
+__device__ __forceinline__ void state_copy(YState *dst, const YState *src) {
+    static_assert(sizeof(YState) % 16 == 0, "YState is copied as int4 words");
+    const int4 *s4 = reinterpret_cast<const int4 *>(src);
+    int4 *d4 = reinterpret_cast<int4 *>(dst);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(YState) / 16; i++) d4[i] = s4[i];
+}
+
+// 16-byte row load; nt = non-temporal (streaming) cache policy
+__device__ __forceinline__ double2 ld_row(const double *p, bool nt) {
+    if (nt) return make_double2(__builtin_nontemporal_load(p), __builtin_nontemporal_load(p + 1));
+    return *reinterpret_cast<const double2 *>(p);
+}
+
+// By-value selects: a reference + runtime element index would turn into a dynamically indexed
+// private array, which hipcc places in scratch / LDS instead of registers.
+__device__ __forceinline__ double elem(double2 v, int e) {
+    const double a = v.x, b = v.y;
+    return e ? b : a;
+}
+__device__ __forceinline__ double2 with_elem(double2 v, int e, double x) {
+    return make_double2(e ? v.x : x, e ? x : v.y);
+}

@@ -1,0 +1,510 @@
+// resident_kernel.cuh -- persistent kernel, tableau resident in the register files
+// Part of libyalps_hip.so; included by yalps_hip.hip inside its anonymous namespace (gfx950 only).
+#pragma once
+
+// ------------------------------------------------------------------------------------------
+// resident_kernel: the whole pivot loop in ONE launch, tableau resident in the register files.
+//
+// Applies when the tableau fits on chip (2049 x 2049 fp64 = 33.6 MB against 128 MB of VGPRs): one
+// workgroup per CU keeps its rows (b, b+NB, ...) in registers for the whole solve; every workgroup
+// also keeps a replica of the objective row.  Per pivot the ONLY traffic is one exchange through
+// L2: every workgroup publishes its candidate (min-ratio row in phase 2, most-negative-RHS row in
+// phase 1) together with that row's data, all workgroups read the NB (key, row) pairs, take the
+// same arg-min and fetch the winner's row.  Nothing is streamed from or to HBM inside the loop.
+//
+// Hand-off = Guideline 16 R1 of the CDNA guide, table row 1: payload stored write-through (agent-
+// scope relaxed atomic stores = sc1), every storing wave drains (s_waitcnt vmcnt(0)), workgroup
+// barrier, ONE lane stores the flag {epoch, row}; consumers poll that one word per producer with
+// sc1 loads, join a workgroup barrier, then read the payload with sc1 loads only.  Buffers are
+// ping-ponged by epoch parity: a workgroup cannot get two epochs ahead of another one because it
+// needs that workgroup's flag of the epoch in between.  Results do not depend on placement or
+// timing: every decision is a deterministic function of bytes that are identical for all readers.
+// Every spin is bounded; a give-up sets rc_err and the host re-runs the chunk with the streaming
+// kernel from the untouched input buffer.
+//
+// The kernel runs at most `chunk` pivots per launch (bounded run time; the host relaunches while
+// the status is RUNNING) and writes the tableau to the OTHER buffer on exit.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void st_sc1(double *p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_sc1(const double *p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p),
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// 16-byte forms (one instruction per lane unit).  hipcc does not count inline-asm memory operations:
+// the store is covered by the publisher's explicit s_waitcnt vmcnt(0), the load waits inside its
+// own statement (CDNA guide 5.7, form (i)).
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st16_sc1(double *p, double2 v) {
+    v2f64 t = {v.x, v.y};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+}
+template <int J>
+__device__ __forceinline__ void ld16_sc1(double2 (&out)[J], const double *base, const int (&ofs)[J]) {
+    static_assert(J == 1 || J == 2 || J == 4, "lane units per row");
+    v2f64 t[J];
+    if constexpr (J == 1) {
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(t[0]) : "v"(base + ofs[0]) : "memory");
+    } else if constexpr (J == 2) {
+        asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(t[0]), "=&v"(t[1])
+                     : "v"(base + ofs[0]), "v"(base + ofs[1])
+                     : "memory");
+    } else {
+        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
+                     "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3])
+                     : "v"(base + ofs[0]), "v"(base + ofs[1]), "v"(base + ofs[2]), "v"(base + ofs[3])
+                     : "memory");
+    }
+#pragma unroll
+    for (int j = 0; j < J; j++) out[j] = make_double2(t[j].x, t[j].y);
+}
+
+template <int T, int J, int R>
+__global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chunk) {
+    __shared__ double sk[2][16];
+    __shared__ int si[2][16];
+    __shared__ double sh_val[R + 2]; // per-row broadcast: pivot-column entry / entering-column entry
+    __shared__ double sh_nq[R + 2];  // -coef/quotient per row (:36), for the objective row, 1/quotient (:25)
+    __shared__ double sh_ck;         // my candidate for the next exchange: key, row, local slot
+    __shared__ int sh_ci, sh_cg, sh_fail;
+    extern __shared__ int sh_perm[]; // workgroup 0: var[perm_len] then pos[perm_len]
+
+    const int tid = threadIdx.x, NB = d.nb, b = blockIdx.x;
+    const YState *Sin = d.st + parity;
+    YState *Sout = d.st + (parity ^ 1);
+    const YConst *C = d.cst;
+    if (Sin->status != RUNNING) {
+        if (b == 0 && tid == 0) state_copy(Sout, Sin);
+        return;
+    }
+    const int h = C->height, n = d.n, pitch = d.pitch, w = d.w;
+    const double precision = C->precision, max_pivots = C->max_pivots;
+    const int mbuf = Sin->mbuf;
+    const double *matA = d.mat[mbuf];
+    const double *rhsA = d.rhs[mbuf];
+    int phase = Sin->phase;
+    double iter = Sin->iter;
+    int64_t pivots = Sin->pivots;
+    int slot = 0;
+
+    int cofs[J];
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+        const int c0 = 2 * (tid + j * T);
+        cofs[j] = c0 < pitch ? c0 : 0;
+    }
+    // ---- load my rows, the objective replica, my rows' RHS (lane g), the basis (workgroup 0) ----
+    double2 x[R][J], o[J];
+#pragma unroll
+    for (int j = 0; j < J; j++) o[j] = *reinterpret_cast<const double2 *>(matA + cofs[j]);
+#pragma unroll
+    for (int g = 0; g < R; g++) {
+        const int r = b + NB * g;
+        const double *mr = matA + (size_t)(r < h ? r : b) * pitch;
+#pragma unroll
+        for (int j = 0; j < J; j++) x[g][j] = *reinterpret_cast<const double2 *>(mr + cofs[j]);
+    }
+    const int my_r = b + NB * tid; // lane g = tid < R owns the scalar side of row g
+    const bool my_live = tid < R && my_r < h;
+    double my_rhs = rhsA[my_live ? my_r : 0];
+    if (b == 0) {
+        for (int i = tid; i < d.perm_len; i += T) {
+            sh_perm[i] = d.var[i];
+            sh_perm[d.perm_len + i] = d.pos[i];
+        }
+    }
+    if (tid == 0) sh_fail = 0;
+    __syncthreads();
+
+    // ---- building blocks of one round ------------------------------------------------------------
+    int la = 0; // entering column of the NEXT pivot (phase 2), priced on my objective replica
+    // Dantzig pricing (src/simplex.ts:71-79) on my replica of the objective row -> la
+    auto price = [&]() __attribute__((always_inline)) {
+        KI best = {INFINITY, INT_MAX};
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            const int c0 = 2 * (tid + j * T);
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const double ov = elem(o[j], k);
+                if (c0 + k < n && ov > precision && ki_better(-ov, c0 + k + 1, best.k, best.i)) {
+                    best.k = -ov;
+                    best.i = c0 + k + 1;
+                }
+            }
+        }
+        best = block_argmin<T>(best, sk, si, slot);
+        slot ^= 1;
+        la = best.i == INT_MAX ? 0 : best.i;
+    };
+    // lanes 0..R-1: candidate of my row of the given kind (1 = most negative RHS, 2 = min ratio with
+    // the row's entry in column la taken from sh_val[lane]), reduced over the workgroup and left in
+    // sh_ck / sh_ci / sh_cg for every lane
+    auto candidate = [&](int kind) __attribute__((always_inline)) {
+        KI c = {INFINITY, INT_MAX};
+        if (my_live && my_r >= 1) {
+            if (kind == 1) {
+                if (my_rhs < -precision) {
+                    c.k = my_rhs;
+                    c.i = my_r;
+                }
+            } else if (la > 0) {
+                const double value = sh_val[tid];
+                if (value > precision) {
+                    const double ratio = my_rhs / value;
+                    if (ratio < INFINITY) {
+                        c.k = (ratio <= precision) ? -INFINITY : ratio;
+                        c.i = my_r;
+                    }
+                }
+            }
+        }
+        if (tid < 64) {
+            c = wave_argmin(c);
+            if (tid == 0) {
+                sh_ck = c.k;
+                sh_ci = c.i;
+                sh_cg = c.i == INT_MAX ? 0 : c.i / NB;
+            }
+        }
+        __syncthreads();
+    };
+    unsigned epoch = 0;
+    // publish my candidate (sh_ck / sh_ci) and the data of its row (register slot sh_cg)
+    auto publish = [&]() __attribute__((always_inline)) {
+        epoch++;
+        const int par = epoch & 1, cg = sh_cg;
+        double2 v[J];
+#pragma unroll
+        for (int j = 0; j < J; j++) v[j] = x[0][j];
+        // v = x[cg] as a chain of register selects.  The empty asm keeps hipcc from rewriting the chain
+        // into a dynamically indexed load, which would move all my rows from registers to scratch.
+#pragma unroll
+        for (int g = 1; g < R; g++) {
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                double ax = x[g][j].x, ay = x[g][j].y;
+                asm volatile("" : "+v"(ax), "+v"(ay));
+                v[j].x = g == cg ? ax : v[j].x;
+                v[j].y = g == cg ? ay : v[j].y;
+            }
+        }
+        double *dst = d.rc_rows[par] + (size_t)b * pitch;
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            const int c0 = 2 * (tid + j * T);
+            if (c0 < pitch) st16_sc1(dst + c0, v[j]);
+        }
+        if (tid == cg) st_sc1(d.rc_key[par] + b, my_rhs); // the candidate row's RHS entry (lane cg)
+        if (tid == 0) // the key travels next to the flag: one 16-byte record per workgroup
+            __hip_atomic_store(d.rc_flag[par] + 2 * b, (unsigned long long)__double_as_longlong(sh_ck), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains ...
+        __syncthreads();                                  // ... before ONE lane raises the flag
+        if (tid == 0)
+            __hip_atomic_store(d.rc_flag[par] + 2 * b + 1, ((unsigned long long)epoch << 32) | (unsigned)sh_ci,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // entries of my rows in column la, as the rows are now -> sh_val[0..R)
+    auto column_la = [&]() __attribute__((always_inline)) {
+        const int ula = (la - 1) >> 1, ela = (la - 1) & 1;
+        if (la > 0 && tid == ula % T) {
+#pragma unroll
+            for (int g = 0; g < R; g++)
+#pragma unroll
+                for (int j = 0; j < J; j++)
+                    if (j == ula / T) sh_val[g] = elem(x[g][j], ela);
+        }
+        __syncthreads();
+    };
+    int done = 0, term = RUNNING;
+    double term_result = NAN;
+    bool stop = false;
+    // loop bound, optimality: checked before every exchange (src/simplex.ts:69,109 and :80)
+    auto check = [&]() __attribute__((always_inline)) {
+        if (done == chunk) {
+            stop = true;
+        } else if (!(iter < max_pivots)) {
+            term = YALPS_CYCLED;
+            stop = true;
+        } else if (phase == 2 && la == 0) {
+            term = YALPS_OPTIMAL;
+            stop = true;
+        }
+    };
+
+    // first round: candidates from the tableau as loaded
+    price();
+    column_la();
+    check();
+    if (!stop) {
+        candidate(phase);
+        publish();
+    }
+    // (single back edge, single exit: every `stop` is a flag, so the rows stay in one set of registers)
+    while (!stop) {
+        // ---------------- gather everyone's candidate -------------------------------------------
+        const int par = epoch & 1;
+        KI c = {INFINITY, INT_MAX};
+        if (tid < NB) {
+            // The key word was stored and drained before the flag word of the same 16-byte record,
+            // and is read AFTER the poll matched (program order of two sc1 loads of one lane).
+            unsigned long long f = 0;
+            unsigned spins = 0;
+            for (;;) {
+                f = __hip_atomic_load(d.rc_flag[par] + 2 * tid + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(f >> 32) == epoch) break;
+                if (++spins > (1u << 22) || __hip_atomic_load(d.rc_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    sh_fail = 1;
+                    __hip_atomic_store(d.rc_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            c.i = (int)(unsigned)f;
+            c.k = __longlong_as_double((long long)__hip_atomic_load(d.rc_flag[par] + 2 * tid, __ATOMIC_RELAXED,
+                                                                    __HIP_MEMORY_SCOPE_AGENT));
+        }
+        c = block_argmin<T>(c, sk, si, slot); // (its barrier is the one the polling waves join)
+        slot ^= 1;
+        if (sh_fail) return; // uniform: written before the barrier above
+        if (c.i == INT_MAX) {
+            if (phase == 1) { // :120 phase 1 is over: same tableau, now the min-ratio exchange
+                phase = 2;
+                iter = 0.0;
+                check();
+                if (!stop) {
+                    column_la(); // my rows are complete here: their entries of column la
+                    candidate(2);
+                    publish();
+                }
+            } else {
+                term = YALPS_UNBOUNDED; // :96
+                term_result = (double)la;
+                stop = true;
+            }
+            continue;
+        }
+        const int row = c.i, owner = row % NB;
+        // ---------------- the winner's raw row (sc1 loads only) ----------------------------------
+        const double *src = d.rc_rows[par] + (size_t)owner * pitch;
+        const double rhs_row = ld_sc1(d.rc_key[par] + owner);
+        double2 pv[J];
+        ld16_sc1<J>(pv, src, cofs);
+        int col = la;
+        if (phase == 1) { // :123-134
+            KI e = {INFINITY, INT_MAX};
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                const int c0 = 2 * (tid + j * T);
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const double coefficient = elem(pv[j], k);
+                    if (c0 + k < n && coefficient < -precision) {
+                        const double ratio = -elem(o[j], k) / coefficient;
+                        if (ratio > -INFINITY && ki_better(-ratio, c0 + k + 1, e.k, e.i)) {
+                            e.k = -ratio;
+                            e.i = c0 + k + 1;
+                        }
+                    }
+                }
+            }
+            e = block_argmin<T>(e, sk, si, slot);
+            slot ^= 1;
+            if (e.i == INT_MAX) { // :135
+                term = YALPS_INFEASIBLE;
+                stop = true;
+                continue;
+            }
+            col = e.i;
+        }
+        // ---------------- pivot (src/simplex.ts:5-39) on my registers ----------------------------
+        // Order: everything the NEXT exchange needs first (objective replica -> la, my rows' entries
+        // of column la and RHS -> my candidate, that one row), publish, and only then the other rows:
+        // their elimination overlaps the time the flags take to travel.
+        const int ucol = (col - 1) >> 1, ecol = (col - 1) & 1, col_tid = ucol % T, col_j = ucol / T;
+        if (tid == col_tid) { // pivot-column entries of my rows, of the objective row, the quotient
+#pragma unroll
+            for (int j = 0; j < J; j++)
+                if (j == col_j) {
+#pragma unroll
+                    for (int g = 0; g < R; g++) sh_val[g] = elem(x[g][j], ecol);
+                    sh_val[R] = elem(o[j], ecol);
+                    sh_val[R + 1] = elem(pv[j], ecol);
+                }
+        }
+        __syncthreads();
+        const double q = sh_val[R + 1], coef0 = sh_val[R];
+        double cf[R]; // uniform: pivot-column entry of each of my rows
+#pragma unroll
+        for (int g = 0; g < R; g++) cf[g] = sh_val[g];
+        unsigned nzmask = 0;
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const double v = elem(pv[j], k);
+                const bool nz = fabs(v) > 1e-16;
+                pv[j] = with_elem(pv[j], k, nz ? v / q : 0.0);
+                if (nz) nzmask |= 1u << (2 * j + k);
+            }
+        }
+        const bool nz_rhs = fabs(rhs_row) > 1e-16;
+        const int lslot = owner == b ? row / NB : -1; // my register slot of the pivot row, if I own it
+        // the R + 2 divisions of the pivot column (one per lane of wave 0, not R+2 per lane)
+        if (tid < R + 2) sh_nq[tid] = tid == R + 1 ? 1.0 / q : -sh_val[tid] / q;
+        if (my_live) { // RHS entry of my row (:33 at column 0)
+            const double pn_rhs = nz_rhs ? rhs_row / q : 0.0;
+            double my_coef = 0.0;
+#pragma unroll
+            for (int g = 0; g < R; g++)
+                if (tid == g) my_coef = cf[g];
+            if (tid == lslot)
+                my_rhs = pn_rhs;
+            else if (fabs(my_coef) > 1e-16 && nz_rhs) {
+                const double prod = my_coef * pn_rhs;
+                my_rhs = my_rhs - prod;
+            }
+        }
+        const bool touched0 = fabs(coef0) > 1e-16;
+        if (touched0) { // my replica of the objective row (branch-free over the lane's columns)
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                const double px = coef0 * pv[j].x, py = coef0 * pv[j].y;
+                const double nx = o[j].x - px, ny = o[j].y - py;
+                o[j].x = (nzmask & (1u << (2 * j))) ? nx : o[j].x;
+                o[j].y = (nzmask & (1u << (2 * j + 1))) ? ny : o[j].y;
+            }
+        }
+        __syncthreads(); // sh_nq visible; sh_val (pivot column) consumed
+        if (touched0 && tid == col_tid) {
+#pragma unroll
+            for (int j = 0; j < J; j++)
+                if (j == col_j) o[j] = with_elem(o[j], ecol, sh_nq[R]);
+        }
+        // my rows, fully, as pivot() leaves them: slot `only` (only_it = true) or all slots but it
+        auto finish_rows = [&](int only, bool only_it) __attribute__((always_inline)) {
+#pragma unroll
+            for (int g = 0; g < R; g++) { // (g must stay a compile-time index: the rows are registers)
+            if ((g == only) != only_it) continue;
+            if (g == lslot) {
+#pragma unroll
+                for (int j = 0; j < J; j++) {
+                    x[g][j] = pv[j];
+                    if (tid == col_tid && j == col_j) x[g][j] = with_elem(x[g][j], ecol, sh_nq[R + 1]); // :25
+                }
+            } else if (b + NB * g < h && fabs(cf[g]) > 1e-16) { // :31 (uniform per row)
+#pragma unroll
+                for (int j = 0; j < J; j++) {
+                    const double px = cf[g] * pv[j].x, py = cf[g] * pv[j].y;
+                    const double nx = x[g][j].x - px, ny = x[g][j].y - py;
+                    x[g][j].x = (nzmask & (1u << (2 * j))) ? nx : x[g][j].x;
+                    x[g][j].y = (nzmask & (1u << (2 * j + 1))) ? ny : x[g][j].y;
+                    if (tid == col_tid && j == col_j) x[g][j] = with_elem(x[g][j], ecol, sh_nq[g]); // :36
+                }
+            }
+            }
+        };
+        iter += 1.0;
+        pivots += 1;
+        done += 1;
+        price(); // la of the next pivot, from the updated objective replica
+        check();
+        if (!stop) {
+            if (phase == 2) {
+                // my rows' entries of column la AFTER this pivot, computed by the lane that holds them
+                const int ula = (la - 1) >> 1, ela = (la - 1) & 1;
+                if (tid == ula % T) {
+#pragma unroll
+                    for (int j = 0; j < J; j++)
+                        if (j == ula / T) {
+                            const double p = elem(pv[j], ela);
+                            const bool nz = (nzmask >> (2 * j + ela)) & 1u;
+#pragma unroll
+                            for (int g = 0; g < R; g++) {
+                                double v = elem(x[g][j], ela);
+                                if (g == lslot)
+                                    v = la == col ? sh_nq[R + 1] : p;
+                                else if (b + NB * g < h && fabs(cf[g]) > 1e-16) {
+                                    if (la == col)
+                                        v = sh_nq[g];
+                                    else if (nz) {
+                                        const double prod = cf[g] * p;
+                                        v = v - prod;
+                                    }
+                                }
+                                sh_val[g] = v;
+                            }
+                        }
+                }
+                __syncthreads();
+            }
+            candidate(phase);
+            const int cg = sh_cg;
+            finish_rows(cg, true);
+            publish();
+            finish_rows(cg, false);
+        } else {
+            finish_rows(-1, false);
+        }
+        if (b == 0 && tid == 0) { // basis bookkeeping, :7-12, in LDS (off the critical path)
+            int *var = sh_perm, *pos = sh_perm + d.perm_len;
+            const int leaving = var[w + row], entering = var[col];
+            var[w + row] = entering;
+            var[col] = leaving;
+            pos[leaving] = col;
+            pos[entering] = w + row;
+        }
+        // (no barrier here: the next write to sh_val / sh_nq comes after the gather's barrier, which every
+        // wave reaches only after it has finished reading them)
+    }
+
+    // ---------------- leave: tableau to the other buffer, state, basis ---------------------------
+    double *matB = d.mat[mbuf ^ 1];
+    double *rhsB = d.rhs[mbuf ^ 1];
+#pragma unroll
+    for (int g = 0; g < R; g++) {
+        const int r = b + NB * g;
+        if (r < h) {
+            double *mr = matB + (size_t)r * pitch;
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                const int c0 = 2 * (tid + j * T);
+                if (c0 < pitch) *reinterpret_cast<double2 *>(mr + c0) = x[g][j];
+            }
+        }
+    }
+    if (my_live) rhsB[my_r] = my_rhs;
+    if (b == 0) {
+        for (int i = tid; i < d.perm_len; i += T) {
+            d.var[i] = sh_perm[i];
+            d.pos[i] = sh_perm[d.perm_len + i];
+        }
+        if (tid == 0) {
+            if (term == YALPS_OPTIMAL) term_result = round_to_precision(my_rhs, precision); // lane 0 = row 0
+            Sout->status = term;
+            Sout->phase = phase;
+            Sout->bootstrap = 1; // the streaming kernel would have to re-scan
+            Sout->la = 0;
+            Sout->pbuf = 0;
+            Sout->mbuf = mbuf ^ 1;
+            Sout->pause = 0;
+            Sout->dec_valid = 0;
+            Sout->dec_row = 0;
+            Sout->dec_col = 0;
+            Sout->swap_valid = 0;
+            Sout->swap_row = 0;
+            Sout->swap_col = 0;
+            Sout->pad_ = 0;
+            Sout->hist_len = 0;
+            Sout->iter = iter;
+            Sout->result = term_result;
+            Sout->pivots = pivots;
+        }
+    }
+}
