@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""bench_table.py -- the reference README's benchmark table (README.md:276-373, whole-solve() times of
+11 problems) re-measured with the MI355X core behind the same API (lite).
+
+For every problem: the model is read from the reference's own data files (tests/golden), the
+tableau is built by the Python mirror of tableauModel (NOT timed: in an integration that stays the
+TypeScript host's job), and what is timed is what this build replaces: the simplex() calls --
+  lp_ms     one drop-in call yalps_simplex_f64 on host arrays (upload + solve + download), root LP
+  milp_ms   the whole branch and cut: sequential (one drop-in call per node) and batched (node_batch=32)
+next to the reference's published whole-solve() mean (unknown CPU, node 19) for orientation only.
+Prints one JSON object.
+"""
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+README_MS = {"Monster 2": 53.95, "Monster Problem": 1.85, "Vendor Selection": 296.05, "Large Farm MIP": 30.46,
+             "AGG2": 1.6, "BEACONFD": 2.59, "SC205": 7.18, "SCFXM1": 20.67, "SCRS8": 56.8, "SCTAP2": 49.98,
+             "SHIP08S": 17.86}
+
+
+def main():
+    from tests import _cases as K, _golden as G
+    from yalps_amd import _native, model as M, mps, solve as S
+    netlib = {b["name"]: b for b in mps.read_benchmarks(os.path.join(G.GOLDEN, "netlib"))}
+    rows = []
+    for name, ref_ms in README_MS.items():
+        if name in netlib:
+            b = netlib[name]
+            mdl, opt, expected = b["model"], dict(b["options"]), b["expected"]
+        else:
+            c = K.load(name)
+            mdl, opt, expected = c["model"], dict(c["options"]), c["expected"]["result"]
+        opt["maxPivots"] = math.inf  # benchmarks/runners.ts:10
+        tm = M.tableau_model(mdl)
+        t = tm.tableau
+        lp = []
+        for _ in range(5):
+            m, pos, var = t.matrix.copy(), t.position_of_variable.copy(), t.variable_at_position.copy()
+            t0 = time.perf_counter()
+            st, res, piv = _native.simplex_host(m, t.width, t.height, pos, var, precision=opt["precision"],
+                                                max_pivots=opt["maxPivots"], check_cycles=opt["checkCycles"])
+            lp.append(time.perf_counter() - t0)
+        row = {"problem": name, "tableau": "%dx%d" % (t.height, t.width), "integers": len(tm.integers),
+               "root_status": st, "root_pivots": piv, "lp_ms": round(1e3 * min(lp), 3),
+               "us_per_pivot": round(1e6 * min(lp) / max(piv, 1), 2), "reference_solve_ms_readme": ref_ms}
+        if tm.integers:
+            for label, nb in (("milp_sequential_ms", 0), ("milp_batched_ms", 32)):
+                ts = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    sol = S.solve(mdl, opt, node_batch=nb)
+                    ts.append(time.perf_counter() - t0)
+                row[label] = round(1e3 * min(ts), 2)  # includes the Python host (tableau build, heap, cuts)
+            row["objective_ok"] = bool(K.result_is_optimal(sol["result"], expected, S.default_options | {"tolerance": opt.get("tolerance", 0)}))
+        rows.append(row)
+    print(json.dumps({"what": "simplex() time behind solve() on 1 MI355X vs the reference README table", "rows": rows}))
+
+
+if __name__ == "__main__":
+    main()

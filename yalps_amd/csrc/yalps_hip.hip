@@ -80,8 +80,10 @@ struct RVariant {
 const RVariant kResident[] = {
     // few, fat lanes: the loop is latency-bound, and <= 8 waves per CU leave each lane 256 VGPRs
     RVARIANT(256, 1, 4), RVARIANT(256, 1, 9), RVARIANT(256, 1, 16), RVARIANT(256, 2, 4), RVARIANT(256, 2, 9),
-    RVARIANT(256, 2, 16), RVARIANT(512, 2, 4), RVARIANT(512, 2, 9), RVARIANT(512, 2, 16), RVARIANT(512, 4, 4),
-    RVARIANT(512, 4, 9),
+    RVARIANT(256, 2, 16), RVARIANT(512, 2, 4), RVARIANT(512, 2, 6), RVARIANT(512, 2, 9), RVARIANT(512, 2, 16),
+    RVARIANT(512, 4, 4), RVARIANT(512, 4, 6), RVARIANT(512, 4, 9),
+    // (<512,2,16>, <512,4,6> and <512,4,9> spill a little at the 256-VGPR cap of an 8-wave workgroup; they
+    // still beat streaming: 1477x2388 runs at 25 us/pivot resident against 27 (wide) / 47 (pivot_kernel))
 };
 #undef RVARIANT
 constexpr int RESIDENT_CHUNK = 4096; // pivots per launch of the resident kernel (bounds its run time)
@@ -363,7 +365,9 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
         if (v.R >= (forceR ? forceR : rows_per_block)) break;
     }
     t->var = *pick;
-    if (J >= 4 || rows_per_block > pick->R || env_int("YALPS_HIP_WIDE", 0)) {
+    // (pivot_kernel's <1024,2,*> variants spill at the 128-VGPR cap: 47 us/pivot on a 1477x2388 tableau
+    // against 27 us for wide_kernel)
+    if (J >= 4 || (T == 1024 && J >= 2) || rows_per_block > pick->R || env_int("YALPS_HIP_WIDE", 0)) {
         for (const WVariant &v : kWide)
             if (v.T == T && v.J == J) t->wfn = v.fn;
         t->wshmem = sizeof(double) * ((size_t)((n + 15) / 16 * 16 < 16 ? 16 : (n + 15) / 16 * 16) + 2 * (size_t)rows_per_block);
