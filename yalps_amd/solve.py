@@ -24,6 +24,8 @@ _DEFAULTS = {
 
 default_options = dict(_DEFAULTS)  # a copy, like the reference's exported `defaultOptions` (:65)
 
+NODE_BATCH_MAX_BYTES = 4 << 20  # root tableaux above this size are never batched (see _solve_with)
+
 
 def round_to_precision(num, precision):
     """src/util.ts:1-4 with JS Math.round (halves toward +infinity)."""
@@ -82,7 +84,10 @@ def _solve_with(simplex, model, options=None, node_batch=0, stats=None):
     status, result = simplex(tabmod.tableau, opt)
     if not tabmod.integers or status != "optimal":
         return solution(tabmod, status, result, opt)
-    if node_batch > 1 and not opt["checkCycles"]:
+    # one workgroup per node only pays while a node's tableau is small (it streams through one CU);
+    # large roots (Vendor Selection: 23 MB) are better off on the whole-chip kernels, one node at a time
+    small = tabmod.tableau.matrix.nbytes <= NODE_BATCH_MAX_BYTES
+    if node_batch > 1 and not opt["checkCycles"] and small:
         from .branch_and_cut import branch_and_cut_batched
         int_tabmod, int_status, int_result = branch_and_cut_batched(tabmod, result, opt, node_batch, stats)
     else:
