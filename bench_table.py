@@ -6,6 +6,7 @@ For every problem: the model is read from the reference's own data files (tests/
 tableau is built by the Python mirror of tableauModel (NOT timed: in an integration that stays the
 TypeScript host's job), and what is timed is what this build replaces: the simplex() calls --
   lp_ms     one drop-in call yalps_simplex_f64 on host arrays (upload + solve + download), root LP
+  lp_sparse_ms  the same LP through yalps_simplex_sparse_f64 (cells up, column 0 + permutations back)
   milp_ms   the whole branch and cut: sequential (one drop-in call per node) and batched (node_batch=32)
 next to the reference's published whole-solve() mean (unknown CPU, node 19) for orientation only.
 Prints one JSON object.
@@ -48,8 +49,17 @@ def main():
             st, res, piv = _native.simplex_host(m, t.width, t.height, pos, var, precision=opt["precision"],
                                                 max_pivots=opt["maxPivots"], check_cycles=opt["checkCycles"])
             lp.append(time.perf_counter() - t0)
+        cells = M.tableau_model(mdl, sparse=True).tableau.cells
+        sp = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            st2, res2, piv2, _, _, _ = _native.simplex_sparse(t.width, t.height, *cells, precision=opt["precision"],
+                                                              max_pivots=opt["maxPivots"], check_cycles=opt["checkCycles"])
+            sp.append(time.perf_counter() - t0)
+        assert (st2, piv2) == (st, piv) and (res2 == res or (res2 != res2 and res != res))
         row = {"problem": name, "tableau": "%dx%d" % (t.height, t.width), "integers": len(tm.integers),
-               "root_status": st, "root_pivots": piv, "lp_ms": round(1e3 * min(lp), 3),
+               "root_status": st, "root_pivots": piv, "lp_ms": round(1e3 * min(lp), 3), "lp_sparse_ms": round(1e3 * min(sp), 3),
+               "cells": int(cells[0].size),
                "us_per_pivot": round(1e6 * min(lp) / max(piv, 1), 2), "reference_solve_ms_readme": ref_ms}
         if tm.integers:
             for label, nb in (("milp_sequential_ms", 0), ("milp_batched_ms", 32)):

@@ -63,6 +63,16 @@ int32_t yalps_simplex_f64_ex(double *matrix, int32_t width, int32_t height,
                              double precision, double maxPivots, int32_t checkCycles,
                              int32_t copyback, double *result_out, int64_t *pivots_out);
 
+/* tableauModel -> simplex -> solution for a pure LP without a dense host tableau: the initial
+ * tableau arrives as its written cells (see yalps_tableau_assemble), and only what solution()
+ * reads comes back (src/YALPS.ts:18-19,32): column 0 (height doubles) and both permutations
+ * (width+height int32 each). */
+int32_t yalps_simplex_sparse_f64(int32_t width, int32_t height, int64_t nnz, const int32_t *row,
+                                 const int32_t *col, const double *val, double precision,
+                                 double maxPivots, int32_t checkCycles, double *col0_out,
+                                 int32_t *pos_out, int32_t *var_out, double *result_out,
+                                 int64_t *pivots_out);
+
 /* ---- device-resident tableaux (HBM) -------------------------------------------------------
  * For callers that keep the tableau on the GPU between calls (benchmarks, branch-and-cut node
  * evaluation: src/branchAndCut.ts:126-127 re-solves root+cuts per node). */
@@ -83,6 +93,14 @@ void yalps_tableau_destroy(yalps_tableau *t);
 /* Host -> HBM: row-major width*height doubles + the two permutations (width+height int32). */
 int32_t yalps_tableau_upload(yalps_tableau *t, const double *matrix, int32_t height,
                              const int32_t *positionOfVariable, const int32_t *variableAtPosition);
+/* On-device assembly of an INITIAL tableau (what src/tableau.ts:87-134 builds):
+ * rows [0,height) are zeroed in HBM, the `nnz` cells (row[i], col[i]) = val[i] are scattered
+ * (column 0 = RHS column, row 0 = objective row) and both permutations are set to the identity
+ * (src/tableau.ts:95-98).  Cells must be sorted by (row, col), strictly increasing -- the host
+ * resolves the reference's "a later coefficient overwrites an earlier one" (:101-115) before the
+ * call.  Moves 16*nnz bytes over PCIe instead of 8*width*height. */
+int32_t yalps_tableau_assemble(yalps_tableau *t, int32_t height, int64_t nnz, const int32_t *row,
+                               const int32_t *col, const double *val);
 /* HBM -> host; any of the three pointers may be NULL to skip it. */
 int32_t yalps_tableau_download(yalps_tableau *t, double *matrix, int32_t *positionOfVariable,
                                int32_t *variableAtPosition);

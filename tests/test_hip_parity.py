@@ -202,3 +202,62 @@ def test_resident_chunking_and_repeatability(nat, ctx, oracle):
         assert t.info()["last_path"] == "resident"
     finally:
         t.close()
+
+
+# ---- on-device tableau assembly -------------------------------------------
+def _cells(m, w):
+    idx = np.flatnonzero(m.view(np.int64) != 0)  # every cell that is not +0.0 (a -0.0 cell is kept: bit-exact)
+    return (idx // w).astype(np.int32), (idx % w).astype(np.int32), m[idx]
+
+
+@pytest.mark.parametrize("rec", [pytest.param(r, id=G.label(r)) for r in G.records("cases")])
+def test_assemble_then_solve_matches_reference_golden(nat, ctx, oracle, rec):
+    """yalps_tableau_assemble builds the reference's initial tableau in HBM from its non-zero cells
+    (bit-identical matrix, identity permutations), and yalps_simplex_sparse_f64 returns the
+    reference's status / result / pivot count / column 0 / permutations."""
+    w, h = rec["width"], rec["height"]
+    m = G.initial_matrix(rec, oracle)
+    row, col, val = _cells(m, w)
+    t = nat.DeviceTableau(ctx, w, h + 3)  # spare capacity: stale rows beyond `height` must not matter
+    try:
+        junk = np.full(w * (h + 3), 7.5)
+        t.upload(junk, h + 3, np.arange(w + h + 3, dtype=np.int32)[::-1].copy(), np.arange(w + h + 3, dtype=np.int32)[::-1].copy())
+        t.assemble(h, row, col, val)
+        got, pos, var = t.download()
+    finally:
+        t.close()
+    assert t.capacity == h + 3 and got.size == w * h
+    assert np.array_equal(got.view(np.int64), m.view(np.int64))
+    assert np.array_equal(pos, np.arange(w + h)) and np.array_equal(var, np.arange(w + h))
+    exp = G.expected(rec)
+    status, result, npiv, col0, pos, var = nat.simplex_sparse(w, h, row, col, val, **G.options(rec))
+    assert (status, npiv) == (exp["status"], exp["n_pivots"]) and G.same_number(result, exp["result"])
+    assert np.array_equal(pos, exp["pos"]) and np.array_equal(var, exp["var"])
+    assert np.array_equal(col0.view(np.int64), exp["col0"].view(np.int64))
+
+
+def test_assemble_rejects_bad_cells(nat, ctx):
+    t = nat.DeviceTableau(ctx, 4, 3)
+    i32, f64 = lambda *a: np.array(a, np.int32), lambda *a: np.array(a, np.float64)
+    try:
+        for row, col in ((i32(1, 1), i32(2, 2)), (i32(2, 1), i32(0, 0)), (i32(0, 3), i32(0, 0)), (i32(0, 0), i32(1, 4)),
+                         (i32(-1, 0), i32(0, 1))):
+            with pytest.raises(nat.NativeError):
+                t.assemble(3, row, col, f64(1, 2))
+        t.assemble(3, i32(), i32(), f64())  # no cells: the all-zero tableau
+        got, pos, var = t.download()
+        assert not got.any() and pos.tolist() == list(range(7))
+    finally:
+        t.close()
+
+
+def test_solve_sparse_equals_dense_on_netlib(nat):
+    """solve(): the sparse route (cells up, column 0 + permutations back) returns the same Solution
+    as the dense host tableau through yalps_simplex_f64."""
+    from yalps_amd import mps, solve as S
+    for b in mps.read_benchmarks(os.path.join(G.GOLDEN, "netlib")):
+        if b["name"] not in ("SC105", "SC205", "AGG2", "SCTAP1", "SCAGR7", "BEACONFD", "KLEIN2"):
+            continue
+        a = S.solve(b["model"], b["options"], sparse=True)
+        d = S.solve(b["model"], b["options"], sparse=False)
+        assert a["status"] == d["status"] and G.same_number(a["result"], d["result"]) and a["variables"] == d["variables"]

@@ -116,3 +116,29 @@ def test_round_to_precision_matches_oracle(oracle):
             a, b = S.round_to_precision(x, p), oracle.round_to_precision(x, p)
             assert G.same_number(a, b), (x, p, a, b)
     assert math.isnan(S.round_to_precision(1.0, 0.0))
+
+
+@pytest.mark.parametrize("name", K.names())
+def test_sparse_tableau_model_same_cells(name):
+    """tableau_model(sparse=True): the written cells, sorted by (row, col) without
+    duplicates, rebuild the reference's initial tableau bit for bit."""
+    rec = CASE_RECORDS[name]
+    tm = M.tableau_model(K.load(name)["model"], sparse=True)
+    t = tm.tableau
+    assert t.matrix is None and (t.width, t.height) == (rec["width"], rec["height"])
+    row, col, val = t.cells
+    assert row.dtype == np.int32 and col.dtype == np.int32 and val.dtype == np.float64
+    flat = row.astype(np.int64) * t.width + col
+    assert np.all(np.diff(flat) > 0) and (flat.size == 0 or (flat[0] >= 0 and flat[-1] < t.width * t.height))
+    assert G.sha256(t.dense()) == rec["init_sha256"]
+    assert tm.sign == rec["sign"] and tm.integers == rec["integers"]
+
+
+def test_sparse_tableau_model_last_duplicate_wins():
+    """src/tableau.ts:101-115: a later coefficient for the same (variable, constraint) overwrites."""
+    model = {"objective": "p", "constraints": [("a", {"max": 4}), ("a", {"min": 1}), ("b", {"max": 9})],
+             "variables": [("x", [("a", 1.0), ("p", 2.0), ("a", 3.0)]), ("y", [("b", 5.0), ("b", 0.0), ("p", 7.0)])]}
+    dense, sparse = M.tableau_model(model), M.tableau_model(model, sparse=True)
+    assert np.array_equal(sparse.tableau.dense(), dense.tableau.matrix)
+    assert dense.tableau.matrix.reshape(dense.tableau.height, -1).tolist() == \
+        [[0, 2, 7], [4, 3, 0], [-1, -3, 0], [9, 0, 0]]

@@ -22,7 +22,7 @@ SYMBOLS = (
     "yalps_tableau_solve", "yalps_tableau_pivot", "yalps_tableau_bench_sweep", "yalps_dense_lp_f64",
     "yalps_round_to_precision", "yalps_ctx_create_on_stream", "yalps_tableau_set_shard", "yalps_shard_slot_doubles",
     "yalps_shard_begin", "yalps_shard_select", "yalps_shard_apply", "yalps_shard_poll", "yalps_tableau_info",
-    "yalps_batch_create", "yalps_batch_destroy", "yalps_batch_set_root", "yalps_batch_solve", "yalps_batch_download",
+    "yalps_tableau_assemble", "yalps_simplex_sparse_f64", "yalps_batch_create", "yalps_batch_destroy", "yalps_batch_set_root", "yalps_batch_solve", "yalps_batch_download",
 )
 
 
@@ -48,6 +48,11 @@ def lib():
         L.yalps_simplex_f64_ex.restype = C.c_int32
         L.yalps_simplex_f64_ex.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, C.c_double, C.c_double, C.c_int32,
                                            C.c_int32, f64p, C.POINTER(C.c_int64)]
+        L.yalps_simplex_sparse_f64.restype = C.c_int32
+        L.yalps_simplex_sparse_f64.argtypes = [C.c_int32, C.c_int32, C.c_int64, vp, vp, vp, C.c_double, C.c_double,
+                                               C.c_int32, vp, vp, vp, f64p, C.POINTER(C.c_int64)]
+        L.yalps_tableau_assemble.restype = C.c_int32
+        L.yalps_tableau_assemble.argtypes = [vp, C.c_int32, C.c_int64, vp, vp, vp]
         L.yalps_ctx_create.restype = C.c_int32
         L.yalps_ctx_create.argtypes = [C.c_int32, C.POINTER(vp)]
         L.yalps_ctx_create_on_stream.restype = C.c_int32
@@ -133,6 +138,20 @@ def simplex_host(matrix, width, height, pos, var, precision=1e-8, max_pivots=819
     return STATUS[st], res.value, npiv.value
 
 
+def simplex_sparse(width, height, row, col, val, precision=1e-8, max_pivots=8192.0, check_cycles=False):
+    """Initial tableau given by its written cells (sorted by (row, col)); assembled and solved in HBM.
+    Returns (status, result, n_pivots, col0, positionOfVariable, variableAtPosition)."""
+    assert row.size == col.size == val.size
+    col0 = np.empty(height, np.float64)
+    pos, var = np.empty(width + height, np.int32), np.empty(width + height, np.int32)
+    res, npiv = C.c_double(), C.c_int64()
+    st = check(lib().yalps_simplex_sparse_f64(width, height, row.size, _ptr(row, np.int32), _ptr(col, np.int32),
+                                              _ptr(val, np.float64), precision, float(max_pivots),
+                                              int(bool(check_cycles)), col0.ctypes.data, pos.ctypes.data,
+                                              var.ctypes.data, C.byref(res), C.byref(npiv)))
+    return STATUS[st], res.value, npiv.value, col0, pos, var
+
+
 class Context:
     def __init__(self, device=0, stream=None):
         """stream: an existing HIP stream handle (int) to enqueue on, e.g.
@@ -165,6 +184,12 @@ class DeviceTableau:
         assert matrix.size >= self.width * height and pos.size >= self.width + height
         check(lib().yalps_tableau_upload(self.handle, _ptr(matrix, np.float64), height, _ptr(pos, np.int32),
                                          _ptr(var, np.int32)))
+
+    def assemble(self, height, row, col, val):
+        """Initial tableau from its written cells, sorted by (row, col) (yalps_tableau_assemble)."""
+        assert row.size == col.size == val.size
+        check(lib().yalps_tableau_assemble(self.handle, height, row.size, _ptr(row, np.int32), _ptr(col, np.int32),
+                                           _ptr(val, np.float64)))
 
     def download(self, matrix=True, perms=True, perm_len=None):
         h, w = self.height, self.width

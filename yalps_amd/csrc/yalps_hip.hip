@@ -21,6 +21,7 @@
 // first-wins comparisons in every scan.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <climits>
 #include <cmath>
 #include <cstdint>
@@ -41,6 +42,7 @@ namespace {
 #include "pivot_kernel.cuh"
 #include "wide_kernel.cuh"
 #include "shard_kernels.cuh"
+#include "assemble_kernels.cuh"
 #include "resident_kernel.cuh"
 #include "batch_kernel.cuh"
 
@@ -148,6 +150,8 @@ struct yalps_tableau {
     hipEvent_t slot_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int32_t *hist[2] = {nullptr, nullptr};
     int64_t hist_cap = 0;
+    void *cells = nullptr; // staging of yalps_tableau_assemble: row[] col[] val[] of cells_cap entries
+    int64_t cells_cap = 0;
 };
 
 namespace {
@@ -458,7 +462,7 @@ void yalps_tableau_destroy(yalps_tableau *t) {
     Desc &d = t->d;
     void *bufs[] = {d.mat[0], d.mat[1], d.rhs[0], d.rhs[1], d.pos, d.var, d.st, d.cst, d.rc_rows[0], d.rc_rows[1], t->perm_backup,
                     d.rc_key[0], d.rc_key[1], d.rc_flag[0], d.rc_flag[1], d.rc_err, d.part_ratio[0], d.part_ratio[1], d.part_rhs[0], d.part_rhs[1],
-                    t->hist[0], t->hist[1]};
+                    t->hist[0], t->hist[1], t->cells};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (t->host_state) (void)hipHostFree(t->host_state);
@@ -532,6 +536,50 @@ int32_t yalps_tableau_download_rhs(yalps_tableau *t, double *col0) {
     hipStream_t s = t->ctx->stream;
     HIP_TRY(hipMemcpyAsync(col0, t->d.rhs[t->cur], sizeof(double) * (size_t)t->height, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+int32_t yalps_tableau_assemble(yalps_tableau *t, int32_t height, int64_t nnz, const int32_t *row, const int32_t *col,
+                               const double *val) {
+    if (!t || nnz < 0 || (nnz > 0 && (!row || !col || !val)))
+        return fail(YALPS_E_ARG, "yalps_tableau_assemble: NULL argument");
+    if (height < 1 || height > t->d.hcap) return fail(YALPS_E_ARG, "yalps_tableau_assemble: height exceeds capacity");
+    if (t->d.nshards > 1) return fail(YALPS_E_ARG, "yalps_tableau_assemble: tableau is sharded; create a new one");
+    if (nnz > INT32_MAX) return fail(YALPS_E_ARG, "yalps_tableau_assemble: too many cells");
+    const Desc &d = t->d;
+    for (int64_t i = 0; i < nnz; i++) { // in range and strictly increasing in (row, col): no cell twice
+        if (row[i] < 0 || row[i] >= height || col[i] < 0 || col[i] >= d.w)
+            return fail(YALPS_E_ARG, "yalps_tableau_assemble: cell outside the tableau");
+        if (i > 0 && (row[i] < row[i - 1] || (row[i] == row[i - 1] && col[i] <= col[i - 1])))
+            return fail(YALPS_E_ARG, "yalps_tableau_assemble: cells must be sorted by (row, column) without duplicates");
+    }
+    HIP_TRY(hipSetDevice(t->ctx->device));
+    hipStream_t s = t->ctx->stream;
+    if (nnz > t->cells_cap) {
+        if (t->cells) HIP_TRY(hipFree(t->cells));
+        t->cells = nullptr;
+        t->cells_cap = 0;
+        const int64_t cap = nnz + nnz / 2 + 1024;
+        HIP_TRY(hipMalloc(&t->cells, (size_t)cap * 16));
+        t->cells_cap = cap;
+    }
+    double *dval = static_cast<double *>(t->cells);
+    int32_t *drow = reinterpret_cast<int32_t *>(dval + t->cells_cap), *dcol = drow + t->cells_cap;
+    t->cur = 0;
+    t->perm_len = d.w + height;
+    t->d.perm_len = t->perm_len;
+    const size_t total = (size_t)height * d.pitch / 2;
+    const int clear_blocks = (int)std::min<size_t>((total + 255) / 256, (size_t)t->ctx->num_cus * 8);
+    assemble_clear_kernel<<<dim3(clear_blocks < 1 ? 1 : clear_blocks), dim3(256), 0, s>>>(t->d, height);
+    if (nnz > 0) {
+        HIP_TRY(hipMemcpyAsync(dval, val, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(drow, row, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(dcol, col, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, s));
+        assemble_scatter_kernel<<<dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, s>>>(t->d, (int)nnz, drow, dcol, dval);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    t->height = height;
     return 0;
 }
 
@@ -988,14 +1036,9 @@ namespace {
 std::mutex g_default_mu;
 yalps_ctx *g_default_ctx = nullptr;
 yalps_tableau *g_default_tab = nullptr;
-} // namespace
 
-int32_t yalps_simplex_f64_ex(double *matrix, int32_t width, int32_t height, int32_t *pos, int32_t *var,
-                             double precision, double maxPivots, int32_t checkCycles, int32_t copyback,
-                             double *result_out, int64_t *pivots_out) {
-    if (!matrix || !pos || !var || width < 1 || height < 1)
-        return fail(YALPS_E_ARG, "yalps_simplex_f64: bad argument");
-    std::lock_guard<std::mutex> lock(g_default_mu);
+// the process-wide tableau behind the host-array entry points (g_default_mu held by the caller)
+int default_tableau(int32_t width, int32_t height, yalps_tableau **out) {
     int rc;
     if (!g_default_ctx) {
         rc = yalps_ctx_create(env_int("YALPS_HIP_DEVICE", 0), &g_default_ctx);
@@ -1009,6 +1052,20 @@ int32_t yalps_simplex_f64_ex(double *matrix, int32_t width, int32_t height, int3
         if (rc) return rc;
         g_default_tab = t;
     }
+    *out = t;
+    return 0;
+}
+} // namespace
+
+int32_t yalps_simplex_f64_ex(double *matrix, int32_t width, int32_t height, int32_t *pos, int32_t *var,
+                             double precision, double maxPivots, int32_t checkCycles, int32_t copyback,
+                             double *result_out, int64_t *pivots_out) {
+    if (!matrix || !pos || !var || width < 1 || height < 1)
+        return fail(YALPS_E_ARG, "yalps_simplex_f64: bad argument");
+    std::lock_guard<std::mutex> lock(g_default_mu);
+    yalps_tableau *t = nullptr;
+    int rc = default_tableau(width, height, &t);
+    if (rc) return rc;
     rc = yalps_tableau_upload(t, matrix, height, pos, var);
     if (rc) return rc;
     const int32_t status = yalps_tableau_solve(t, precision, maxPivots, checkCycles, result_out, pivots_out, nullptr);
@@ -1022,6 +1079,27 @@ int32_t yalps_simplex_f64_ex(double *matrix, int32_t width, int32_t height, int3
     } else {
         rc = yalps_tableau_download(t, matrix, pos, var);
     }
+    if (rc) return rc;
+    return status;
+}
+
+int32_t yalps_simplex_sparse_f64(int32_t width, int32_t height, int64_t nnz, const int32_t *row, const int32_t *col,
+                                 const double *val, double precision, double maxPivots, int32_t checkCycles,
+                                 double *col0_out, int32_t *pos_out, int32_t *var_out, double *result_out,
+                                 int64_t *pivots_out) {
+    if (width < 1 || height < 1 || !col0_out || !pos_out || !var_out)
+        return fail(YALPS_E_ARG, "yalps_simplex_sparse_f64: bad argument");
+    std::lock_guard<std::mutex> lock(g_default_mu);
+    yalps_tableau *t = nullptr;
+    int rc = default_tableau(width, height, &t);
+    if (rc) return rc;
+    rc = yalps_tableau_assemble(t, height, nnz, row, col, val);
+    if (rc) return rc;
+    const int32_t status = yalps_tableau_solve(t, precision, maxPivots, checkCycles, result_out, pivots_out, nullptr);
+    if (status < 0) return status;
+    rc = yalps_tableau_download_rhs(t, col0_out);
+    if (rc) return rc;
+    rc = yalps_tableau_download(t, nullptr, pos_out, var_out);
     if (rc) return rc;
     return status;
 }

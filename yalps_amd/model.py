@@ -25,6 +25,16 @@ class Tableau:
     position_of_variable: np.ndarray
     variable_at_position: np.ndarray
     col0: np.ndarray = None  # RHS column alone, when only that was copied back from the GPU (matrix may be None)
+    cells: tuple = None  # (row, col, val) of the cells tableauModel wrote, sorted by (row, col), when the
+    #                      tableau was built sparse (matrix is None until dense() or the GPU fills col0)
+
+    def dense(self):
+        """The row-major matrix of a tableau built with sparse=True."""
+        if self.matrix is None:
+            row, col, val = self.cells
+            self.matrix = np.zeros(self.width * self.height, np.float64)
+            self.matrix[row.astype(np.int64) * self.width + col] = val
+        return self.matrix
 
     def rhs(self, row):
         """index(tableau, row, 0)"""
@@ -72,8 +82,20 @@ def _get(constraint, name):
     return None if v is None else float(v)
 
 
-def tableau_model(model):
-    """src/tableau.ts:47-137, line for line in behaviour."""
+class _Cells(dict):
+    """Stand-in for the zeroed Float64Array while the model is walked: flat index -> last value written."""
+
+    def arrays(self, width):
+        idx = np.fromiter(self.keys(), np.int64, len(self))
+        val = np.fromiter(self.values(), np.float64, len(self))
+        order = np.argsort(idx, kind="stable")
+        idx, val = idx[order], val[order]
+        return (idx // width).astype(np.int32), (idx % width).astype(np.int32), val
+
+
+def tableau_model(model, sparse=False):
+    """src/tableau.ts:47-137, line for line in behaviour.  sparse=True keeps only the cells the
+    reference writes into its zeroed matrix (Tableau.cells; for yalps_tableau_assemble)."""
     sign = -1.0 if model.get("direction") == "minimize" else 1.0  # :51
     objective = model.get("objective")
     integers, binaries = model.get("integers"), model.get("binaries")
@@ -112,7 +134,7 @@ def tableau_model(model):
     width = len(variables) + 1
     height = num_constraints + len(binary_constraint_col)
     num_vars = width + height
-    m = np.zeros(width * height, np.float64)
+    m = _Cells() if sparse else np.zeros(width * height, np.float64)
     pos = np.arange(num_vars, dtype=np.int32)  # :95-98 identity
     var = np.arange(num_vars, dtype=np.int32)
 
@@ -143,6 +165,8 @@ def tableau_model(model):
         m[row * width] = 1.0
         m[row * width + col] = 1.0
 
+    if sparse:
+        return TableauModel(Tableau(None, width, height, pos, var, cells=m.arrays(width)), sign, variables, ints)
     return TableauModel(Tableau(m, width, height, pos, var), sign, variables, ints)
 
 

@@ -46,7 +46,15 @@ def round_to_precision(num, precision):
 
 def hip_simplex(tableau, options):
     """The drop-in for src/simplex.ts:144 `simplex(tableau, options)`: in place, through the C ABI
-    (yalps_simplex_f64).  Returns (status, result)."""
+    (yalps_simplex_f64).  Returns (status, result).  A tableau built with sparse=True that has no
+    dense matrix yet goes up as its written cells and only column 0 + the permutations come back
+    (yalps_simplex_sparse_f64) -- all that solution() reads (src/YALPS.ts:18-19,32)."""
+    if tableau.matrix is None:
+        row, col, val = tableau.cells
+        status, result, _, tableau.col0, tableau.position_of_variable, tableau.variable_at_position = \
+            _native.simplex_sparse(tableau.width, tableau.height, row, col, val, precision=options["precision"],
+                                   max_pivots=options["maxPivots"], check_cycles=options["checkCycles"])
+        return status, result
     status, result, _ = _native.simplex_host(
         tableau.matrix, tableau.width, tableau.height, tableau.position_of_variable, tableau.variable_at_position,
         precision=options["precision"], max_pivots=options["maxPivots"], check_cycles=options["checkCycles"])
@@ -74,10 +82,12 @@ def solution(tabmod, status, result, options):
     return {"status": status, "result": math.nan, "variables": []}  # infeasible | cycled | timedout w/o result
 
 
-def _solve_with(simplex, model, options=None, node_batch=0, stats=None):
+def _solve_with(simplex, model, options=None, node_batch=0, stats=None, sparse=False):
     """src/YALPS.ts:73-92 with the simplex backend as a parameter (tests drive the host logic
     with the CPU oracle through this; the product binds the HIP backend below)."""
-    tabmod = tableau_model(model)
+    tabmod = tableau_model(model, sparse=sparse)
+    if sparse and tabmod.integers:
+        tabmod.tableau.dense()  # branch and cut reads the whole root matrix (src/branchAndCut.ts:28,38-41)
     opt = dict(_DEFAULTS)
     if options:
         opt.update({k: v for k, v in options.items() if v is not None})
@@ -86,7 +96,7 @@ def _solve_with(simplex, model, options=None, node_batch=0, stats=None):
         return solution(tabmod, status, result, opt)
     # one workgroup per node only pays while a node's tableau is small (it streams through one CU);
     # large roots (Vendor Selection: 23 MB) are better off on the whole-chip kernels, one node at a time
-    small = tabmod.tableau.matrix.nbytes <= NODE_BATCH_MAX_BYTES
+    small = 8 * tabmod.tableau.width * tabmod.tableau.height <= NODE_BATCH_MAX_BYTES
     if node_batch > 1 and not opt["checkCycles"] and small:
         from .branch_and_cut import branch_and_cut_batched
         int_tabmod, int_status, int_result = branch_and_cut_batched(tabmod, result, opt, node_batch, stats)
@@ -95,11 +105,15 @@ def _solve_with(simplex, model, options=None, node_batch=0, stats=None):
     return solution(int_tabmod, int_status, int_result, opt)
 
 
-def solve(model, options=None, node_batch=0, stats=None):
+def solve(model, options=None, node_batch=0, stats=None, sparse=True):
     """Runs the solver on `model` (see yalps_amd.model) with `options` (keys as in the reference's
     `Options`, src/types.ts:203-265).  Returns {"status", "result", "variables": [(key, value)]}.
 
     node_batch > 1: branch and cut evaluates that many frontier nodes per GPU batch (speculatively,
     best first; results are committed in the reference's pop order, so the outcome is the same as
-    node_batch = 0, which re-solves one node at a time through the drop-in simplex call)."""
-    return _solve_with(hip_simplex, model, options, node_batch, stats)
+    node_batch = 0, which re-solves one node at a time through the drop-in simplex call).
+
+    sparse: a model without integer variables is shipped as the cells tableauModel writes and its
+    tableau is assembled in HBM (same tableau, same pivots, 16 B per cell over PCIe instead of
+    8*width*height); False = always the dense host tableau."""
+    return _solve_with(hip_simplex, model, options, node_batch, stats, sparse)
