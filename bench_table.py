@@ -9,7 +9,10 @@ TypeScript host's job), and what is timed is what this build replaces: the simpl
   lp_sparse_ms  the same LP through yalps_simplex_sparse_f64 (cells up, column 0 + permutations back)
   milp_ms   the whole branch and cut: sequential (one drop-in call per node) and batched (node_batch=32)
 next to the reference's published whole-solve() mean (unknown CPU, node 19) for orientation only.
-Prints one JSON object.
+Then the reference's own harness (benchmarks/benchmark.ts, restated in yalps_amd/benchmark.py: 30
+samples per runner, compensated mean / stdDev / slowdown, validated results) over the same problems
+with whole-solve() runners -- these include the Python host (tableau_model, heap, cuts), which in an
+integration is the TypeScript host's work.  Tables go to stderr; prints one JSON object.
 """
 import json
 import math
@@ -31,7 +34,7 @@ def main():
     from tests import _cases as K, _golden as G
     from yalps_amd import _native, model as M, mps, solve as S
     netlib = {b["name"]: b for b in mps.read_benchmarks(os.path.join(G.GOLDEN, "netlib"))}
-    rows = []
+    rows, benches = [], []
     for name, ref_ms in README_MS.items():
         if name in netlib:
             b = netlib[name]
@@ -39,6 +42,7 @@ def main():
         else:
             c = K.load(name)
             mdl, opt, expected = c["model"], dict(c["options"]), c["expected"]["result"]
+        benches.append({"name": name, "model": mdl, "options": {**S.default_options, **opt}, "expected": expected})
         opt["maxPivots"] = math.inf  # benchmarks/runners.ts:10
         tm = M.tableau_model(mdl)
         t = tm.tableau
@@ -71,7 +75,12 @@ def main():
                 row[label] = round(1e3 * min(ts), 2)  # includes the Python host (tableau build, heap, cuts)
             row["objective_ok"] = bool(K.result_is_optimal(sol["result"], expected, S.default_options | {"tolerance": opt.get("tolerance", 0)}))
         rows.append(row)
-    print(json.dumps({"what": "simplex() time behind solve() on 1 MI355X vs the reference README table", "rows": rows}))
+    from yalps_amd import benchmark as B
+    samples = int(os.environ.get("YALPS_BENCH_SAMPLES", "30"))
+    tables = B.benchmark(benches, B.runners, num_samples=samples, out=lambda line: print(line, file=sys.stderr))
+    print(json.dumps({"what": "simplex() time behind solve() on 1 MI355X vs the reference README table", "rows": rows,
+                      "harness": {"samples": samples, "unit": "ms per solve() incl. the Python host",
+                                  "tables": [{"benchmark": h, "results": t} for h, t in tables]}}))
 
 
 if __name__ == "__main__":

@@ -48,9 +48,14 @@ def _collect_nodes(oracle, tabmod, init_result, options, limit):
     return nodes
 
 
+@pytest.mark.parametrize("lds", [True, False], ids=["lds", "hbm"])
 @pytest.mark.parametrize("name", ["Knapsack 1", "Large Farm MIP", "Fancy Stock Cutting Problem", "Integer Sports Complex Problem"])
-def test_batch_nodes_match_oracle(nat, oracle, name):
+def test_batch_nodes_match_oracle(nat, oracle, name, lds, monkeypatch):
+    """lds: the node tableaux fit in LDS and batch_kernel<.., true> solves them there; hbm: the same
+    nodes with YALPS_HIP_NO_LDS=1 (read when the batch is created) in the HBM workspace."""
     from tests.test_host_model import oracle_backend
+    if not lds:
+        monkeypatch.setenv("YALPS_HIP_NO_LDS", "1")
     case = K.load(name)
     opt = case["options"]
     tabmod = M.tableau_model(case["model"])

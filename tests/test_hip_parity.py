@@ -261,3 +261,79 @@ def test_solve_sparse_equals_dense_on_netlib(nat):
         a = S.solve(b["model"], b["options"], sparse=True)
         d = S.solve(b["model"], b["options"], sparse=False)
         assert a["status"] == d["status"] and G.same_number(a["result"], d["result"]) and a["variables"] == d["variables"]
+
+
+# ---- small tableaux: one workgroup, tableau in LDS (small_kernel) --------------------------------
+@pytest.mark.parametrize("M,N,seed", [(3, 2, 1), (35, 100, 2), (99, 149, 3), (60, 290, 4), (1100, 14, 5), (2, 2000, 6)])
+def test_small_path_matches_oracle(nat, ctx, oracle, M, N, seed):
+    """Both variants of small_kernel (256 / 1024 lanes), through the resident-tableau API (HBM
+    layout) and through the host-array drop-in (reference layout in pinned host memory)."""
+    w, h = N + 1, M + 1
+    m = nat.dense_lp(M, N, seed)
+    m[np.random.default_rng(seed).random(m.size) < 0.2] = 0.0
+    m[h // 2 * w] = -3.0  # an infeasible start: phase 1 runs too
+    pos, var = np.arange(w + h, dtype=np.int32), np.arange(w + h, dtype=np.int32)
+    ref, rpos, rvar = m.copy(), pos.copy(), var.copy()
+    est, eres, epiv, _ = oracle.simplex(ref, w, h, rpos, rvar, max_pivots=np.inf)
+    t = nat.DeviceTableau(ctx, w, h)
+    try:
+        t.upload(m, h, pos, var)
+        status, result, npiv, ms = t.solve(max_pivots=np.inf)
+        assert t.info()["last_path"] == "small"
+        got, gpos, gvar = t.download()
+    finally:
+        t.close()
+    assert (status, npiv) == (est, epiv) and G.same_number(result, eres)
+    assert np.array_equal(got.view(np.int64), ref.view(np.int64))
+    assert np.array_equal(gpos, rpos) and np.array_equal(gvar, rvar)
+    hm, hpos, hvar = m.copy(), pos.copy(), var.copy()
+    status, result, npiv = nat.simplex_host(hm, w, h, hpos, hvar, max_pivots=np.inf)
+    assert (status, npiv) == (est, epiv) and G.same_number(result, eres)
+    assert np.array_equal(hm.view(np.int64), ref.view(np.int64))
+    assert np.array_equal(hpos, rpos) and np.array_equal(hvar, rvar)
+    # maxPivots exhausted -> "cycled" with the tableau as it is after that many pivots
+    if epiv > 3:
+        ref2, rpos2, rvar2 = m.copy(), pos.copy(), var.copy()
+        est2, _, epiv2, _ = oracle.simplex(ref2, w, h, rpos2, rvar2, max_pivots=3)
+        hm, hpos, hvar = m.copy(), pos.copy(), var.copy()
+        status, result, npiv = nat.simplex_host(hm, w, h, hpos, hvar, max_pivots=3)
+        assert (status, npiv) == (est2, epiv2) and result != result
+        assert np.array_equal(hm.view(np.int64), ref2.view(np.int64)) and np.array_equal(hpos, rpos2)
+
+
+def test_small_path_boundary(nat, ctx):
+    """Just under / just over the LDS budget: the second one must take the multi-workgroup path."""
+    for (w, h), path in (((101, 180), "small"), ((101, 184), "resident")):
+        m = nat.dense_lp(h - 1, w - 1, 9)
+        t = nat.DeviceTableau(ctx, w, h)
+        try:
+            t.upload(m, h, np.arange(w + h, dtype=np.int32), np.arange(w + h, dtype=np.int32))
+            assert t.solve(max_pivots=np.inf)[0] == "optimal" and t.info()["last_path"] == path
+        finally:
+            t.close()
+
+
+def test_golden_cases_without_small_path(nat, oracle, monkeypatch):
+    """The multi-workgroup kernels (resident, streaming) on the small golden tableaux too: the same
+    records as test_dropin_matches_reference_golden on a context created with YALPS_HIP_SMALL=0."""
+    monkeypatch.setenv("YALPS_HIP_SMALL", "0")
+    c = nat.Context(0)
+    paths = set()
+    try:
+        for rec in G.records("cases") + G.records("mixed"):
+            m = G.initial_matrix(rec, oracle)
+            pos, var = G.identity_perms(rec)
+            exp = G.expected(rec)
+            t = nat.DeviceTableau(c, rec["width"], rec["height"])
+            try:
+                t.upload(m, rec["height"], pos, var)
+                st, res, piv, _ = t.solve(**G.options(rec))
+                paths.add(t.info()["last_path"])
+                gm, gp, gv = t.download()
+            finally:
+                t.close()
+            assert (st, piv) == (exp["status"], exp["n_pivots"]) and G.same_number(res, exp["result"]), G.label(rec)
+            assert G.sha256(gm) == exp["final_sha256"] and np.array_equal(gp, exp["pos"]) and np.array_equal(gv, exp["var"])
+    finally:
+        c.close()
+    assert "small" not in paths and "resident" in paths, paths

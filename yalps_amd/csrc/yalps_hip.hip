@@ -10,6 +10,7 @@
 //                        ping-ponged in HBM; also DECIDE/APPLY for checkCycles
 //   wide_kernel.cuh      streaming for tableaux too wide / tall for register batches (pivot row in LDS)
 //   shard_kernels.cuh    row-sharded solve across GPUs: per-rank select kernel (+ MODE_SHARD above)
+//   wg_simplex.cuh       the whole simplex loop by one workgroup; small_kernel (tableau in LDS)
 //   batch_kernel.cuh     batched branch-and-cut nodes, one workgroup per node
 // Host side here: contexts, tableaux (HBM layout, upload/download), the solve drivers (resident
 // chunks with streaming fallback; hipGraph batches of 64 launches polled once per batch -- no host
@@ -44,6 +45,7 @@ namespace {
 #include "shard_kernels.cuh"
 #include "assemble_kernels.cuh"
 #include "resident_kernel.cuh"
+#include "wg_simplex.cuh"
 #include "batch_kernel.cuh"
 
 // ------------------------------------------------------------------------------------------
@@ -124,6 +126,12 @@ struct yalps_ctx {
     int resident_fault = 0; // test hook: treat the N-th resident launch as failed (YALPS_HIP_RESIDENT_FAULT=N)
     int num_cus = 256;
     int max_blocks = 256; // workgroups per launch (one per CU by default)
+    // single-workgroup LDS path for small tableaux (YALPS_HIP_SMALL=0: never)
+    bool small = true;
+    bool small_attr[2] = {false, false};
+    SmallResult *small_res = nullptr; // pinned, written by the kernel over PCIe
+    void *small_blob = nullptr;       // pinned staging of the host-array entry point: matrix | pos | var
+    size_t small_blob_cap = 0;
 };
 
 struct yalps_tableau {
@@ -308,6 +316,8 @@ static int32_t ctx_create(int32_t device, void *ext_stream, bool adopt, yalps_ct
     c->resident_chunk = env_int("YALPS_HIP_RESIDENT_CHUNK", RESIDENT_CHUNK);
     if (c->resident_chunk < 1) c->resident_chunk = 1;
     c->resident_fault = env_int("YALPS_HIP_RESIDENT_FAULT", 0);
+    c->small = env_int("YALPS_HIP_SMALL", 1) != 0;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->small_res), sizeof(SmallResult), hipHostMallocDefault));
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; // measured 1-2 % faster in the pivot loop at 2049^2 and 4097^2
     c->max_blocks = env_int("YALPS_HIP_BLOCKS", prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
     if (c->max_blocks < 1) c->max_blocks = 1;
@@ -341,6 +351,8 @@ void yalps_ctx_destroy(yalps_ctx *c) {
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
+    if (c->small_res) (void)hipHostFree(c->small_res);
+    if (c->small_blob) (void)hipHostFree(c->small_blob);
     delete c;
 }
 
@@ -481,7 +493,7 @@ int32_t yalps_tableau_info(const yalps_tableau *t, char *buf, int32_t len) {
     std::snprintf(buf, (size_t)len,
                   "streaming=pivot_kernel<%d,%d,%d> workgroups=%d resident=%s last_path=%s last_resident_launches=%lld",
                   t->var.T, t->var.J, t->var.R, t->nb, res,
-                  t->last_path == 1 ? "resident" : t->last_path == 2 ? "streaming" : t->last_path == 3 ? "resident+streaming" : "none",
+                  t->last_path == 1 ? "resident" : t->last_path == 2 ? "streaming" : t->last_path == 3 ? "resident+streaming" : t->last_path == 4 ? "small" : "none",
                   (long long)(t->last_path & 1 ? t->last_launches : 0));
     return 0;
 }
@@ -605,12 +617,65 @@ int32_t yalps_tableau_copy(yalps_tableau *dst, const yalps_tableau *src) {
     return 0;
 }
 
+// One launch of small_kernel on the context's stream and the wait for it; the kernel leaves status /
+// result / pivot count in pinned host memory.
+static int32_t run_small(yalps_ctx *c, SmallDesc sd, double *result_out, int64_t *pivots_out, float *gpu_ms_out) {
+    hipStream_t s = c->stream;
+    const size_t shmem = small_lds_bytes(sd.w, sd.h);
+    const int big = (size_t)sd.h * (size_t)(small_pcols(sd.n) / 2) >= 4096 ? 1 : 0; // 16-byte units to sweep per pivot
+    if (shmem > 48 * 1024 && !c->small_attr[big]) {
+        HIP_TRY(hipFuncSetAttribute(big ? reinterpret_cast<const void *>(small_kernel<1024>)
+                                        : reinterpret_cast<const void *>(small_kernel<256>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMALL_LDS_MAX));
+        c->small_attr[big] = true;
+    }
+    sd.lp = small_lds_pitch(sd.n);
+    sd.res = c->small_res;
+    c->small_res->status = YALPS_E_DEVICE;
+    if (gpu_ms_out) HIP_TRY(hipEventRecord(c->ev0, s));
+    if (big)
+        small_kernel<1024><<<dim3(1), dim3(1024), shmem, s>>>(sd);
+    else
+        small_kernel<256><<<dim3(1), dim3(256), shmem, s>>>(sd);
+    HIP_TRY(hipGetLastError());
+    if (gpu_ms_out) HIP_TRY(hipEventRecord(c->ev1, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (gpu_ms_out) HIP_TRY(hipEventElapsedTime(gpu_ms_out, c->ev0, c->ev1));
+    const SmallResult r = *c->small_res;
+    if (r.status < 0) return fail(YALPS_E_DEVICE, "small_kernel did not report a result");
+    if (result_out) *result_out = r.result;
+    if (pivots_out) *pivots_out = r.pivots;
+    return r.status;
+}
+
+static bool fits_small(const yalps_ctx *c, int32_t w, int32_t h, int32_t checkCycles) {
+    return c->small && !checkCycles && small_lds_bytes(w, h) <= SMALL_LDS_MAX;
+}
+
 int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots, int32_t checkCycles,
                             double *result_out, int64_t *pivots_out, float *gpu_ms_out) {
     if (!t || t->height < 1) return fail(YALPS_E_ARG, "yalps_tableau_solve: no tableau uploaded");
     yalps_ctx *c = t->ctx;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = c->stream;
+    // (0) the tableau fits in the LDS of one CU: one workgroup, one launch, in place
+    if (t->d.nshards == 1 && fits_small(c, t->d.w, t->height, checkCycles)) {
+        SmallDesc sd{};
+        sd.mat = t->d.mat[t->cur];
+        sd.rhs = t->d.rhs[t->cur];
+        sd.pitch = t->d.pitch;
+        sd.rhs_stride = 1;
+        sd.pos = t->d.pos;
+        sd.var = t->d.var;
+        sd.w = t->d.w;
+        sd.n = t->d.n;
+        sd.h = t->height;
+        sd.precision = precision;
+        sd.max_pivots = maxPivots;
+        t->last_path = 4;
+        t->last_launches = 1;
+        return run_small(c, sd, result_out, pivots_out, gpu_ms_out);
+    }
     const int which = checkCycles ? 1 : 0;
     int rc = init_state(t, precision, maxPivots, checkCycles);
     if (rc) return rc;
@@ -881,6 +946,7 @@ struct yalps_batch {
     int32_t *cut_off = nullptr, *cut_sign = nullptr, *cut_var = nullptr;
     double *cut_val = nullptr;
     size_t shmem = 0;
+    bool lds = false; // node tableaux fit in LDS: batch_kernel<.., true>
     int32_t last_count = 0;
 };
 
@@ -899,7 +965,11 @@ static int32_t batch_create_impl(yalps_ctx *ctx, int32_t width, int32_t root_hei
     d.h0 = root_height;
     d.hmax = root_height + max_cuts;
     d.permmax = width + d.hmax;
-    b->shmem = sizeof(double) * ((size_t)d.hmax + d.pitch);
+    const int lp = small_lds_pitch(d.n);
+    const size_t lds_bytes = sizeof(double) * ((size_t)d.hmax * lp + 2 * (size_t)d.hmax + (size_t)lp) +
+                             sizeof(int32_t) * 2 * ((size_t)d.permmax + 1);
+    b->lds = lds_bytes <= SMALL_LDS_MAX && !env_int("YALPS_HIP_NO_LDS", 0);
+    b->shmem = b->lds ? lds_bytes : sizeof(double) * ((size_t)d.hmax + d.pitch);
     if (b->shmem > 150 * 1024) return fail(YALPS_E_ARG, "yalps_batch_create: node tableau too large for the batched path");
     const size_t nm = (size_t)max_nodes;
     HIP_TRY(hipMalloc(&b->root_mat, sizeof(double) * (size_t)d.h0 * d.pitch));
@@ -928,7 +998,8 @@ static int32_t batch_create_impl(yalps_ctx *ctx, int32_t width, int32_t root_hei
     d.cut_var = b->cut_var;
     d.cut_val = b->cut_val;
     if (b->shmem > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(batch_kernel<256>),
+        HIP_TRY(hipFuncSetAttribute(b->lds ? reinterpret_cast<const void *>(batch_kernel<256, true>)
+                                           : reinterpret_cast<const void *>(batch_kernel<256, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->shmem));
     *out = b;
     return 0;
@@ -996,7 +1067,10 @@ int32_t yalps_batch_solve(yalps_batch *b, int32_t count, const int32_t *cut_offs
     b->d.precision = precision;
     b->d.max_pivots = maxPivots;
     HIP_TRY(hipEventRecord(c->ev0, s));
-    batch_kernel<256><<<dim3(count), dim3(256), b->shmem, s>>>(b->d);
+    if (b->lds)
+        batch_kernel<256, true><<<dim3(count), dim3(256), b->shmem, s>>>(b->d);
+    else
+        batch_kernel<256, false><<<dim3(count), dim3(256), b->shmem, s>>>(b->d);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev1, s));
     if (status_out) HIP_TRY(hipMemcpyAsync(status_out, b->d.status, sizeof(int32_t) * (size_t)count, hipMemcpyDeviceToHost, s));
@@ -1038,12 +1112,14 @@ yalps_ctx *g_default_ctx = nullptr;
 yalps_tableau *g_default_tab = nullptr;
 
 // the process-wide tableau behind the host-array entry points (g_default_mu held by the caller)
+int default_ctx() {
+    if (g_default_ctx) return 0;
+    return yalps_ctx_create(env_int("YALPS_HIP_DEVICE", 0), &g_default_ctx);
+}
+
 int default_tableau(int32_t width, int32_t height, yalps_tableau **out) {
-    int rc;
-    if (!g_default_ctx) {
-        rc = yalps_ctx_create(env_int("YALPS_HIP_DEVICE", 0), &g_default_ctx);
-        if (rc) return rc;
-    }
+    int rc = default_ctx();
+    if (rc) return rc;
     yalps_tableau *t = g_default_tab;
     if (!t || t->d.w != width || t->d.hcap < height || t->d.hcap > 4 * height) {
         if (t) yalps_tableau_destroy(t);
@@ -1064,7 +1140,51 @@ int32_t yalps_simplex_f64_ex(double *matrix, int32_t width, int32_t height, int3
         return fail(YALPS_E_ARG, "yalps_simplex_f64: bad argument");
     std::lock_guard<std::mutex> lock(g_default_mu);
     yalps_tableau *t = nullptr;
-    int rc = default_tableau(width, height, &t);
+    int rc = default_ctx();
+    if (rc) return rc;
+    if (fits_small(g_default_ctx, width, height, checkCycles)) {
+        // small tableau: staged in pinned host memory in the reference's own layout; the kernel reads
+        // and writes it there over PCIe (no copies to HBM, one launch, one synchronisation)
+        yalps_ctx *c = g_default_ctx;
+        HIP_TRY(hipSetDevice(c->device));
+        const size_t nm = (size_t)width * height, np = (size_t)width + height;
+        const size_t bytes = sizeof(double) * nm + sizeof(int32_t) * 2 * np;
+        if (bytes > c->small_blob_cap) {
+            if (c->small_blob) HIP_TRY(hipHostFree(c->small_blob));
+            c->small_blob = nullptr;
+            c->small_blob_cap = 0;
+            const size_t cap = bytes < (64u << 10) ? (64u << 10) : 2 * bytes;
+            HIP_TRY(hipHostMalloc(&c->small_blob, cap, hipHostMallocDefault));
+            c->small_blob_cap = cap;
+        }
+        double *bm = static_cast<double *>(c->small_blob);
+        int32_t *bp = reinterpret_cast<int32_t *>(bm + nm), *bv = bp + np;
+        std::memcpy(bm, matrix, sizeof(double) * nm);
+        std::memcpy(bp, pos, sizeof(int32_t) * np);
+        std::memcpy(bv, var, sizeof(int32_t) * np);
+        SmallDesc sd{};
+        sd.mat = bm + 1;
+        sd.rhs = bm;
+        sd.pitch = width;
+        sd.rhs_stride = width;
+        sd.pos = bp;
+        sd.var = bv;
+        sd.w = width;
+        sd.n = width - 1;
+        sd.h = height;
+        sd.precision = precision;
+        sd.max_pivots = maxPivots;
+        const int32_t status = run_small(c, sd, result_out, pivots_out, nullptr);
+        if (status < 0) return status;
+        if (copyback == YALPS_COPYBACK_SOLUTION)
+            for (int32_t r = 0; r < height; r++) matrix[(size_t)r * width] = bm[(size_t)r * width];
+        else
+            std::memcpy(matrix, bm, sizeof(double) * nm);
+        std::memcpy(pos, bp, sizeof(int32_t) * np);
+        std::memcpy(var, bv, sizeof(int32_t) * np);
+        return status;
+    }
+    rc = default_tableau(width, height, &t);
     if (rc) return rc;
     rc = yalps_tableau_upload(t, matrix, height, pos, var);
     if (rc) return rc;

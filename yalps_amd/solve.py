@@ -25,6 +25,8 @@ _DEFAULTS = {
 default_options = dict(_DEFAULTS)  # a copy, like the reference's exported `defaultOptions` (:65)
 
 NODE_BATCH_MAX_BYTES = 4 << 20  # root tableaux above this size are never batched (see _solve_with)
+SPARSE_MIN_BYTES = 128 << 10  # below this the dense tableau goes through the single-workgroup path (small_kernel), which
+#                               reads it in place from pinned host memory: nothing to save by shipping cells
 
 
 def round_to_precision(num, precision):
@@ -86,7 +88,7 @@ def _solve_with(simplex, model, options=None, node_batch=0, stats=None, sparse=F
     """src/YALPS.ts:73-92 with the simplex backend as a parameter (tests drive the host logic
     with the CPU oracle through this; the product binds the HIP backend below)."""
     tabmod = tableau_model(model, sparse=sparse)
-    if sparse and tabmod.integers:
+    if sparse and (tabmod.integers or 8 * tabmod.tableau.width * tabmod.tableau.height <= SPARSE_MIN_BYTES):
         tabmod.tableau.dense()  # branch and cut reads the whole root matrix (src/branchAndCut.ts:28,38-41)
     opt = dict(_DEFAULTS)
     if options:
