@@ -1,5 +1,5 @@
 import time, sys, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from yalps_amd import _native as N, model as M
 from tests import _cases as K
 c = K.load("Large Farm MIP")
