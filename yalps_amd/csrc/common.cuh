@@ -204,10 +204,20 @@ __device__ __forceinline__ void state_copy(YState *dst, const YState *src) {
     for (unsigned i = 0; i < sizeof(YState) / 16; i++) d4[i] = s4[i];
 }
 
-// 16-byte row load; nt = non-temporal (streaming) cache policy
+// 16-byte row load / store; nt = non-temporal (streaming) cache policy, one dwordx4 instruction
+typedef double v2f64 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ double2 ld_row(const double *p, bool nt) {
-    if (nt) return make_double2(__builtin_nontemporal_load(p), __builtin_nontemporal_load(p + 1));
+    if (nt) {
+        const v2f64 v = __builtin_nontemporal_load(reinterpret_cast<const v2f64 *>(p));
+        return make_double2(v.x, v.y);
+    }
     return *reinterpret_cast<const double2 *>(p);
+}
+__device__ __forceinline__ void st_row_nt(double *p, double2 v) {
+    v2f64 t;
+    t.x = v.x;
+    t.y = v.y;
+    __builtin_nontemporal_store(t, reinterpret_cast<v2f64 *>(p));
 }
 
 // By-value selects: a reference + runtime element index would turn into a dynamically indexed

@@ -394,8 +394,7 @@ __global__ __launch_bounds__(T) void pivot_kernel(Desc d, int parity, int mode, 
                     if (act && tid == col_tid && j == col_j) // lane g of wave 0 stores -coef/quotient
                         mr[c0 + (ecol ^ 1)] = elem(x[g][j], ecol ^ 1);
                     else if (force & 64) { // streaming (non-temporal) stores; YALPS_HIP_NT=0 turns them off
-                        __builtin_nontemporal_store(x[g][j].x, mr + c0);
-                        __builtin_nontemporal_store(x[g][j].y, mr + c0 + 1);
+                        st_row_nt(mr + c0, x[g][j]);
                     } else
                         *reinterpret_cast<double2 *>(mr + c0) = x[g][j];
                 }

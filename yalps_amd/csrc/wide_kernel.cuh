@@ -305,8 +305,7 @@ __global__ __launch_bounds__(T) void wide_kernel(Desc d, int parity, int mode, i
             }
             if (c0 == (lax & ~1)) lav[i] = (lax & 1) ? v.y : v.x; // the row's entry in the next entering column
             if (force & 64) {
-                __builtin_nontemporal_store(v.x, mr + c0);
-                __builtin_nontemporal_store(v.y, mr + c0 + 1);
+                st_row_nt(mr + c0, v);
             } else
                 *reinterpret_cast<double2 *>(mr + c0) = v;
         }

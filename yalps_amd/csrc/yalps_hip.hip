@@ -490,9 +490,13 @@ int32_t yalps_tableau_info(const yalps_tableau *t, char *buf, int32_t len) {
     char res[96] = "none";
     if (t->rvar.fn)
         std::snprintf(res, sizeof res, "resident_kernel<%d,%d,%d> chunk=%d", t->rvar.T, t->rvar.J, t->rvar.R, RESIDENT_CHUNK);
-    std::snprintf(buf, (size_t)len,
-                  "streaming=pivot_kernel<%d,%d,%d> workgroups=%d resident=%s last_path=%s last_resident_launches=%lld",
-                  t->var.T, t->var.J, t->var.R, t->nb, res,
+    char str[64];
+    if (t->wfn)
+        std::snprintf(str, sizeof str, "wide_kernel<%d,%d>", t->var.T, t->var.J);
+    else
+        std::snprintf(str, sizeof str, "pivot_kernel<%d,%d,%d>", t->var.T, t->var.J, t->var.R);
+    std::snprintf(buf, (size_t)len, "streaming=%s workgroups=%d resident=%s last_path=%s last_resident_launches=%lld", str,
+                  t->nb, res,
                   t->last_path == 1 ? "resident" : t->last_path == 2 ? "streaming" : t->last_path == 3 ? "resident+streaming" : t->last_path == 4 ? "small" : "none",
                   (long long)(t->last_path & 1 ? t->last_launches : 0));
     return 0;
