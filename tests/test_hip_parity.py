@@ -337,3 +337,30 @@ def test_golden_cases_without_small_path(nat, oracle, monkeypatch):
     finally:
         c.close()
     assert "small" not in paths and "resident" in paths, paths
+
+
+def test_small_path_check_cycles_history_growth(nat, oracle, monkeypatch):
+    """checkCycles on the single-workgroup path: hasCycle runs on the device; when a phase outgrows
+    the history buffer the kernel leaves the tableau untouched and the host reruns it with a larger
+    one (forced here with a first buffer of 8 entries)."""
+    monkeypatch.setenv("YALPS_HIP_SMALL_HIST", "8")
+    c = nat.Context(0)
+    try:
+        for rec in G.records("cases") + G.records("mixed"):
+            if not rec["options"]["checkCycles"]:
+                continue
+            m = G.initial_matrix(rec, oracle)
+            pos, var = G.identity_perms(rec)
+            exp = G.expected(rec)
+            t = nat.DeviceTableau(c, rec["width"], rec["height"])
+            try:
+                t.upload(m, rec["height"], pos, var)
+                st, res, piv, _ = t.solve(**G.options(rec))
+                assert t.info()["last_path"] == "small"
+                gm, gp, gv = t.download()
+            finally:
+                t.close()
+            assert (st, piv) == (exp["status"], exp["n_pivots"]) and G.same_number(res, exp["result"]), G.label(rec)
+            assert G.sha256(gm) == exp["final_sha256"] and np.array_equal(gp, exp["pos"]) and np.array_equal(gv, exp["var"])
+    finally:
+        c.close()

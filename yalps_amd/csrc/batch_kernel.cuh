@@ -77,7 +77,7 @@ __global__ __launch_bounds__(T) void batch_kernel(BatchDesc d) {
     }
     __syncthreads();
 
-    const WgResult out = wg_simplex<T>(mat, rhs, pos, var, colbuf, prow, sk, si, w, n, lp, pcols, h,
+    const WgResult out = wg_simplex<T, false>(mat, rhs, pos, var, colbuf, prow, sk, si, w, n, lp, pcols, h,
                                        wg_unit_lanes(pcols / 2, T), d.precision, d.max_pivots);
     if (LDS) { // the node's final tableau, for yalps_batch_download
         __syncthreads();

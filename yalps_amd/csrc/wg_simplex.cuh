@@ -12,17 +12,24 @@
 // place), the pivot row is normalised into prow (FLUSHED marks entries pivot() zeroed), and the
 // sweep maps lanes to (16-byte column unit, row group): U lanes across the units, T / U row groups.
 // ------------------------------------------------------------------------------------------
+constexpr int WG_HISTORY_FULL = -100; // checkCycles: the pivot history buffer is too short (host grows it and reruns)
+
 struct WgResult {
     int status;
     double result;
     long long pivots;
 };
 
-template <int T>
+// CHECK: options.checkCycles -- hasCycle (src/simplex.ts:44-63) before every pivot; the history of
+// (leaving, entering) variables of the current phase is kept in hist_l / hist_e (hist_cap entries,
+// global memory), every lane tests a share of the candidate cycle lengths.
+template <int T, bool CHECK>
 __device__ __attribute__((always_inline)) WgResult wg_simplex(double *mat, double *rhs, int32_t *pos, int32_t *var,
                                                               double *colbuf, double *prow, double (*sk)[16],
                                                               int (*si)[16], int w, int n, int lp, int pcols, int h,
-                                                              int U, double precision, double max_pivots) {
+                                                              int U, double precision, double max_pivots,
+                                                              int32_t *hist_l = nullptr, int32_t *hist_e = nullptr,
+                                                              long long hist_cap = 0) {
     const int tid = threadIdx.x;
     const int units = pcols / 2;
     const int u0 = tid % U, g0 = tid / U, G = T / U; // U is a power of two <= T
@@ -30,6 +37,7 @@ __device__ __attribute__((always_inline)) WgResult wg_simplex(double *mat, doubl
     int phase = 1;
     WgResult out = {YALPS_CYCLED, NAN, 0};
     double iter = 0.0;
+    long long hist_len = 0; // pivots of the current phase (src/simplex.ts:67,107: one history per phase)
     for (;;) {
         if (!(iter < max_pivots)) break; // "cycled" (:102,141)
         int row = 0, col = 0;
@@ -47,6 +55,7 @@ __device__ __attribute__((always_inline)) WgResult wg_simplex(double *mat, doubl
             if (c.i == INT_MAX) {
                 phase = 2; // :120
                 iter = 0.0;
+                hist_len = 0;
                 continue;
             }
             row = c.i;
@@ -106,6 +115,32 @@ __device__ __attribute__((always_inline)) WgResult wg_simplex(double *mat, doubl
                 break;
             }
             row = c.i;
+        }
+        if (CHECK) { // :98,137
+            if (hist_len >= hist_cap) {
+                out.status = WG_HISTORY_FULL;
+                break;
+            }
+            if (tid == 0) {
+                hist_l[hist_len] = var[w + row];
+                hist_e[hist_len] = var[col];
+            }
+            __syncthreads();
+            const long long len = hist_len + 1;
+            bool found = false;
+            for (long long length = 6 + tid; length <= len / 2 && !found; length += T) {
+                bool cycle = true;
+                for (long long i = 0; i < length; i++) {
+                    const long long item = len - 1 - i;
+                    if (hist_l[item] != hist_l[item - length] || hist_e[item] != hist_e[item - length]) {
+                        cycle = false;
+                        break;
+                    }
+                }
+                found = cycle;
+            }
+            hist_len = len;
+            if (__syncthreads_or(found ? 1 : 0)) break; // "cycled", NaN
         }
         // ---- pivot(row, col): src/simplex.ts:5-39 ----
         for (int r = tid; r < h; r += T) colbuf[r] = mat[(size_t)r * lp + col - 1];
@@ -201,6 +236,8 @@ struct SmallDesc {
     SmallResult *res;
     int32_t w, n, h, lp;          // lp: LDS row pitch in doubles (even, >= pcols)
     double precision, max_pivots;
+    int32_t *hist_l, *hist_e;     // checkCycles: pivot history, hist_cap entries each
+    long long hist_cap;
 };
 
 constexpr size_t SMALL_LDS_MAX = 150 * 1024; // of the 160 KB of LDS per CU
@@ -212,7 +249,7 @@ __host__ __device__ inline size_t small_lds_bytes(int w, int h) {
     return sizeof(double) * ((size_t)h * lp + 2 * (size_t)h + (size_t)lp) + sizeof(int32_t) * 2 * ((size_t)w + h + 1);
 }
 
-template <int T>
+template <int T, bool CHECK>
 __global__ __launch_bounds__(T) void small_kernel(SmallDesc d) {
     __shared__ double sk[2][16];
     __shared__ int si[2][16];
@@ -233,9 +270,14 @@ __global__ __launch_bounds__(T) void small_kernel(SmallDesc d) {
     }
     __syncthreads();
 
-    const WgResult out = wg_simplex<T>(mat, rhs, pos, var, colbuf, prow, sk, si, w, n, lp, pcols, h,
-                                       wg_unit_lanes(pcols / 2, T), d.precision, d.max_pivots);
+    const WgResult out = wg_simplex<T, CHECK>(mat, rhs, pos, var, colbuf, prow, sk, si, w, n, lp, pcols, h,
+                                              wg_unit_lanes(pcols / 2, T), d.precision, d.max_pivots, d.hist_l, d.hist_e,
+                                              d.hist_cap);
     __syncthreads();
+    if (CHECK && out.status == WG_HISTORY_FULL) { // leave the caller's tableau untouched: the host reruns
+        if (tid == 0) d.res->status = WG_HISTORY_FULL;
+        return;
+    }
     for (int r = cg0; r < h; r += CG) {
         double *dst = d.mat + (size_t)r * d.pitch;
         for (int c = cu0; c < n; c += Uc) dst[c] = mat[(size_t)r * lp + c];

@@ -128,7 +128,9 @@ struct yalps_ctx {
     int max_blocks = 256; // workgroups per launch (one per CU by default)
     // single-workgroup LDS path for small tableaux (YALPS_HIP_SMALL=0: never)
     bool small = true;
-    bool small_attr[2] = {false, false};
+    bool small_attr[4] = {false, false, false, false};
+    int32_t *small_hist = nullptr; // checkCycles: 2 x small_hist_cap pivot history of small_kernel
+    long long small_hist_cap = 0;
     SmallResult *small_res = nullptr; // pinned, written by the kernel over PCIe
     void *small_blob = nullptr;       // pinned staging of the host-array entry point: matrix | pos | var
     size_t small_blob_cap = 0;
@@ -317,6 +319,8 @@ static int32_t ctx_create(int32_t device, void *ext_stream, bool adopt, yalps_ct
     if (c->resident_chunk < 1) c->resident_chunk = 1;
     c->resident_fault = env_int("YALPS_HIP_RESIDENT_FAULT", 0);
     c->small = env_int("YALPS_HIP_SMALL", 1) != 0;
+    c->small_hist_cap = env_int("YALPS_HIP_SMALL_HIST", 16384); // first size of the checkCycles history (test hook)
+    if (c->small_hist_cap < 1) c->small_hist_cap = 1;
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->small_res), sizeof(SmallResult), hipHostMallocDefault));
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; // measured 1-2 % faster in the pivot loop at 2049^2 and 4097^2
     c->max_blocks = env_int("YALPS_HIP_BLOCKS", prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
@@ -353,6 +357,7 @@ void yalps_ctx_destroy(yalps_ctx *c) {
     if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
     if (c->small_res) (void)hipHostFree(c->small_res);
     if (c->small_blob) (void)hipHostFree(c->small_blob);
+    if (c->small_hist) (void)hipFree(c->small_hist);
     delete c;
 }
 
@@ -623,27 +628,43 @@ int32_t yalps_tableau_copy(yalps_tableau *dst, const yalps_tableau *src) {
 
 // One launch of small_kernel on the context's stream and the wait for it; the kernel leaves status /
 // result / pivot count in pinned host memory.
-static int32_t run_small(yalps_ctx *c, SmallDesc sd, double *result_out, int64_t *pivots_out, float *gpu_ms_out) {
+static int32_t run_small(yalps_ctx *c, SmallDesc sd, int32_t checkCycles, double *result_out, int64_t *pivots_out,
+                         float *gpu_ms_out) {
     hipStream_t s = c->stream;
     const size_t shmem = small_lds_bytes(sd.w, sd.h);
     const int big = (size_t)sd.h * (size_t)(small_pcols(sd.n) / 2) >= 4096 ? 1 : 0; // 16-byte units to sweep per pivot
-    if (shmem > 48 * 1024 && !c->small_attr[big]) {
-        HIP_TRY(hipFuncSetAttribute(big ? reinterpret_cast<const void *>(small_kernel<1024>)
-                                        : reinterpret_cast<const void *>(small_kernel<256>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMALL_LDS_MAX));
-        c->small_attr[big] = true;
+    const int which = 2 * (checkCycles ? 1 : 0) + big;
+    using Fn = void (*)(SmallDesc);
+    static const Fn fns[4] = {small_kernel<256, false>, small_kernel<1024, false>, small_kernel<256, true>,
+                              small_kernel<1024, true>};
+    if (shmem > 48 * 1024 && !c->small_attr[which]) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fns[which]), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)SMALL_LDS_MAX));
+        c->small_attr[which] = true;
     }
     sd.lp = small_lds_pitch(sd.n);
     sd.res = c->small_res;
-    c->small_res->status = YALPS_E_DEVICE;
     if (gpu_ms_out) HIP_TRY(hipEventRecord(c->ev0, s));
-    if (big)
-        small_kernel<1024><<<dim3(1), dim3(1024), shmem, s>>>(sd);
-    else
-        small_kernel<256><<<dim3(1), dim3(256), shmem, s>>>(sd);
-    HIP_TRY(hipGetLastError());
-    if (gpu_ms_out) HIP_TRY(hipEventRecord(c->ev1, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    for (;;) {
+        if (checkCycles && !c->small_hist) {
+            const long long cap = c->small_hist_cap ? c->small_hist_cap : 16384;
+            HIP_TRY(hipMalloc(&c->small_hist, sizeof(int32_t) * 2 * (size_t)cap));
+            c->small_hist_cap = cap;
+        }
+        sd.hist_l = c->small_hist;
+        sd.hist_e = c->small_hist ? c->small_hist + c->small_hist_cap : nullptr;
+        sd.hist_cap = c->small_hist_cap;
+        c->small_res->status = YALPS_E_DEVICE;
+        fns[which]<<<dim3(1), dim3(big ? 1024 : 256), shmem, s>>>(sd);
+        HIP_TRY(hipGetLastError());
+        if (gpu_ms_out) HIP_TRY(hipEventRecord(c->ev1, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (c->small_res->status != WG_HISTORY_FULL) break;
+        // a phase ran longer than the history buffer: the kernel left the tableau untouched; grow and rerun
+        HIP_TRY(hipFree(c->small_hist));
+        c->small_hist = nullptr;
+        c->small_hist_cap *= 4;
+    }
     if (gpu_ms_out) HIP_TRY(hipEventElapsedTime(gpu_ms_out, c->ev0, c->ev1));
     const SmallResult r = *c->small_res;
     if (r.status < 0) return fail(YALPS_E_DEVICE, "small_kernel did not report a result");
@@ -652,8 +673,8 @@ static int32_t run_small(yalps_ctx *c, SmallDesc sd, double *result_out, int64_t
     return r.status;
 }
 
-static bool fits_small(const yalps_ctx *c, int32_t w, int32_t h, int32_t checkCycles) {
-    return c->small && !checkCycles && small_lds_bytes(w, h) <= SMALL_LDS_MAX;
+static bool fits_small(const yalps_ctx *c, int32_t w, int32_t h) {
+    return c->small && small_lds_bytes(w, h) <= SMALL_LDS_MAX;
 }
 
 int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots, int32_t checkCycles,
@@ -663,7 +684,7 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = c->stream;
     // (0) the tableau fits in the LDS of one CU: one workgroup, one launch, in place
-    if (t->d.nshards == 1 && fits_small(c, t->d.w, t->height, checkCycles)) {
+    if (t->d.nshards == 1 && fits_small(c, t->d.w, t->height)) {
         SmallDesc sd{};
         sd.mat = t->d.mat[t->cur];
         sd.rhs = t->d.rhs[t->cur];
@@ -678,7 +699,7 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
         sd.max_pivots = maxPivots;
         t->last_path = 4;
         t->last_launches = 1;
-        return run_small(c, sd, result_out, pivots_out, gpu_ms_out);
+        return run_small(c, sd, checkCycles, result_out, pivots_out, gpu_ms_out);
     }
     const int which = checkCycles ? 1 : 0;
     int rc = init_state(t, precision, maxPivots, checkCycles);
@@ -1146,7 +1167,7 @@ int32_t yalps_simplex_f64_ex(double *matrix, int32_t width, int32_t height, int3
     yalps_tableau *t = nullptr;
     int rc = default_ctx();
     if (rc) return rc;
-    if (fits_small(g_default_ctx, width, height, checkCycles)) {
+    if (fits_small(g_default_ctx, width, height)) {
         // small tableau: staged in pinned host memory in the reference's own layout; the kernel reads
         // and writes it there over PCIe (no copies to HBM, one launch, one synchronisation)
         yalps_ctx *c = g_default_ctx;
@@ -1178,7 +1199,7 @@ int32_t yalps_simplex_f64_ex(double *matrix, int32_t width, int32_t height, int3
         sd.h = height;
         sd.precision = precision;
         sd.max_pivots = maxPivots;
-        const int32_t status = run_small(c, sd, result_out, pivots_out, nullptr);
+        const int32_t status = run_small(c, sd, checkCycles, result_out, pivots_out, nullptr);
         if (status < 0) return status;
         if (copyback == YALPS_COPYBACK_SOLUTION)
             for (int32_t r = 0; r < height; r++) matrix[(size_t)r * width] = bm[(size_t)r * width];
