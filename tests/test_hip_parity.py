@@ -271,7 +271,7 @@ def test_small_path_matches_oracle(nat, ctx, oracle, M, N, seed):
     w, h = N + 1, M + 1
     m = nat.dense_lp(M, N, seed)
     m[np.random.default_rng(seed).random(m.size) < 0.2] = 0.0
-    m[h // 2 * w] = -3.0  # an infeasible start: phase 1 runs too
+    m[h // 2 * w:(h // 2 + 1) * w] *= -1.0  # a row "-a x <= -b": the start is infeasible, phase 1 runs too
     pos, var = np.arange(w + h, dtype=np.int32), np.arange(w + h, dtype=np.int32)
     ref, rpos, rvar = m.copy(), pos.copy(), var.copy()
     est, eres, epiv, _ = oracle.simplex(ref, w, h, rpos, rvar, max_pivots=np.inf)
@@ -364,3 +364,31 @@ def test_small_path_check_cycles_history_growth(nat, oracle, monkeypatch):
             assert G.sha256(gm) == exp["final_sha256"] and np.array_equal(gp, exp["pos"]) and np.array_equal(gv, exp["var"])
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("M,N,kernel", [(600, 2500, "resident_kernel<512,3,4>"), (1400, 2700, "resident_kernel<512,3,6>"),
+                                        (700, 4300, "resident_kernel<512,5,4>"), (4500, 200, "resident_kernel<512,1,24>"),
+                                        (5000, 700, "resident_kernel<512,1,24>"), (1300, 4300, "resident_kernel<512,5,6>"), (7000, 300, "resident_kernel<512,1,32>"),
+                                        (2100, 2480, "resident_kernel<512,3,9>")])
+def test_resident_variants_match_oracle(nat, ctx, oracle, M, N, kernel):
+    """The odd-J and tall variants of the resident kernel, 200 pivots each against the oracle
+    (maxPivots exhausted -> "cycled" with the tableau as it stands), bit for bit."""
+    w, h = N + 1, M + 1
+    m = nat.dense_lp(M, N, 7)
+    m[(h // 3) * w:(h // 3 + 1) * w] *= -1.0  # a row "-a x <= -b": phase 1 first
+    pos, var = np.arange(w + h, dtype=np.int32), np.arange(w + h, dtype=np.int32)
+    ref, rpos, rvar = m.copy(), pos.copy(), var.copy()
+    est, eres, epiv, _ = oracle.simplex(ref, w, h, rpos, rvar, max_pivots=200)
+    assert epiv >= 200
+    t = nat.DeviceTableau(ctx, w, h)
+    try:
+        t.upload(m, h, pos, var)
+        status, result, npiv, _ = t.solve(max_pivots=200)
+        info = t.info()
+        got, gpos, gvar = t.download()
+    finally:
+        t.close()
+    assert info["last_path"] == "resident" and info["resident"].startswith(kernel), info
+    assert (status, npiv) == (est, epiv) and G.same_number(result, eres)
+    assert np.array_equal(got.view(np.int64), ref.view(np.int64))
+    assert np.array_equal(gpos, rpos) and np.array_equal(gvar, rvar)

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libyalps_hip.so")
+LIB_PATH = os.environ.get("YALPS_HIP_LIB") or os.path.join(HERE, "libyalps_hip.so")  # (same switch as the N-API addon)
 
 STATUS = ("optimal", "infeasible", "unbounded", "cycled")
 COPYBACK_FULL, COPYBACK_SOLUTION = 0, 1

@@ -121,6 +121,11 @@ __device__ __forceinline__ double lane_f64(double v, int lane) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
                             __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
+// a value every lane of the wave holds, moved to scalar registers
+__device__ __forceinline__ double uniform_f64(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
+                            __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
 __device__ __forceinline__ KI row16_argmin(KI v) {
     KI r;
     r.k = row16_min(v.k);

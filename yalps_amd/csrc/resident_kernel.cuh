@@ -44,22 +44,35 @@ __device__ __forceinline__ void st16_sc1(double *p, double2 v) {
 }
 template <int J>
 __device__ __forceinline__ void ld16_sc1(double2 (&out)[J], const double *base, const int (&ofs)[J]) {
-    static_assert(J == 1 || J == 2 || J == 4, "lane units per row");
+    static_assert(J >= 1 && J <= 5, "lane units per row");
     v2f64 t[J];
+#define YLD "global_load_dwordx4 %"
     if constexpr (J == 1) {
-        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(t[0]) : "v"(base + ofs[0]) : "memory");
+        asm volatile(YLD "0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(t[0]) : "v"(base + ofs[0]) : "memory");
     } else if constexpr (J == 2) {
-        asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+        asm volatile(YLD "0, %2, off sc1\n\t" YLD "1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
                      : "=&v"(t[0]), "=&v"(t[1])
                      : "v"(base + ofs[0]), "v"(base + ofs[1])
                      : "memory");
-    } else {
-        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
-                     "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+    } else if constexpr (J == 3) {
+        asm volatile(YLD "0, %3, off sc1\n\t" YLD "1, %4, off sc1\n\t" YLD "2, %5, off sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2])
+                     : "v"(base + ofs[0]), "v"(base + ofs[1]), "v"(base + ofs[2])
+                     : "memory");
+    } else if constexpr (J == 4) {
+        asm volatile(YLD "0, %4, off sc1\n\t" YLD "1, %5, off sc1\n\t" YLD "2, %6, off sc1\n\t" YLD "3, %7, off sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
                      : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3])
                      : "v"(base + ofs[0]), "v"(base + ofs[1]), "v"(base + ofs[2]), "v"(base + ofs[3])
                      : "memory");
+    } else {
+        asm volatile(YLD "0, %5, off sc1\n\t" YLD "1, %6, off sc1\n\t" YLD "2, %7, off sc1\n\t" YLD "3, %8, off sc1\n\t"
+                     YLD "4, %9, off sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4])
+                     : "v"(base + ofs[0]), "v"(base + ofs[1]), "v"(base + ofs[2]), "v"(base + ofs[3]), "v"(base + ofs[4])
+                     : "memory");
     }
+#undef YLD
 #pragma unroll
     for (int j = 0; j < J; j++) out[j] = make_double2(t[j].x, t[j].y);
 }
@@ -342,7 +355,8 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
         const double q = sh_val[R + 1], coef0 = sh_val[R];
         double cf[R]; // uniform: pivot-column entry of each of my rows
 #pragma unroll
-        for (int g = 0; g < R; g++) cf[g] = sh_val[g];
+        for (int g = 0; g < R; g++) // (scalar registers where the VGPR budget of 2 waves per SIMD is short: measured
+            cf[g] = (T >= 512 && J * R >= 24) ? uniform_f64(sh_val[g]) : sh_val[g]; // +5 % at <512,2,9>, -10 % at <512,3,9>)
         unsigned nzmask = 0;
 #pragma unroll
         for (int j = 0; j < J; j++) {

@@ -82,12 +82,20 @@ struct RVariant {
 };
 #define RVARIANT(T, J, R) {T, J, R, resident_kernel<T, J, R>}
 const RVariant kResident[] = {
-    // few, fat lanes: the loop is latency-bound, and <= 8 waves per CU leave each lane 256 VGPRs
-    RVARIANT(256, 1, 4), RVARIANT(256, 1, 9), RVARIANT(256, 1, 16), RVARIANT(256, 2, 4), RVARIANT(256, 2, 9),
-    RVARIANT(256, 2, 16), RVARIANT(512, 2, 4), RVARIANT(512, 2, 6), RVARIANT(512, 2, 9), RVARIANT(512, 2, 16),
+    // few, fat lanes: the loop is latency-bound, and <= 8 waves per CU leave each lane 256 VGPRs.
+    // A tableau takes the feasible variant (T * J 16-byte units span a row, R rows per workgroup) with
+    // the fewest row registers J * R; J = 3 / 5 keep 1025..1536 / 2049..2560 units out of the next power of two.
+    RVARIANT(256, 1, 4), RVARIANT(256, 1, 9), RVARIANT(256, 1, 16),
+    RVARIANT(256, 2, 4), RVARIANT(256, 2, 9),
+    // (no variant may need AGPRs: <256,1,32> (374 registers) left its last row slots unwritten on the
+    // GPU; tests/test_cabi_symbols.py checks the register counts of the built code object)
+    RVARIANT(512, 1, 24), RVARIANT(512, 1, 32), // tall and narrow: 17..32 rows per workgroup
+    RVARIANT(512, 2, 4), RVARIANT(512, 2, 6), RVARIANT(512, 2, 9), RVARIANT(512, 2, 16),
+    RVARIANT(512, 3, 4), RVARIANT(512, 3, 6), RVARIANT(512, 3, 9), // (<512,3,12> spills 450 B: 34 us/pivot at 2561^2, wide_kernel 27)
     RVARIANT(512, 4, 4), RVARIANT(512, 4, 6), RVARIANT(512, 4, 9),
+    RVARIANT(512, 5, 4), RVARIANT(512, 5, 6),
     // (<512,2,16>, <512,4,6> and <512,4,9> spill a little at the 256-VGPR cap of an 8-wave workgroup; they
-    // still beat streaming: 1477x2388 runs at 25 us/pivot resident against 27 (wide) / 47 (pivot_kernel))
+    // still beat streaming)
 };
 #undef RVARIANT
 constexpr int RESIDENT_CHUNK = 4096; // pivots per launch of the resident kernel (bounds its run time)
@@ -432,12 +440,14 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
     if (t->nb <= ctx->num_cus) {
         // (16 waves per CU were tried for 2049^2: <1024,1,9> spills at the 128-VGPR cap and its barriers
         // cost more: 92 K pivots/s against 144 K for <512,2,9>)
-        const int rT = units <= 512 ? 256 : 512;
-        const int rJ = units <= 256 ? 1 : units <= 1024 ? 2 : 4;
+        int best = INT_MAX;
         for (const RVariant &v : kResident) {
-            if (units > 2048 || v.T != rT || v.J != rJ || v.R < rows_per_block) continue;
-            t->rvar = v;
-            break;
+            if (v.T * v.J < units || v.R < rows_per_block) continue;
+            const int regs = v.J * v.R * 1024 + v.T; // fewest row registers, then fewest waves
+            if (regs < best) {
+                best = regs;
+                t->rvar = v;
+            }
         }
     }
     if (t->rvar.fn) {
