@@ -368,7 +368,8 @@ def test_small_path_check_cycles_history_growth(nat, oracle, monkeypatch):
 
 @pytest.mark.parametrize("M,N,kernel", [(600, 2500, "resident_kernel<512,3,4>"), (1400, 2700, "resident_kernel<512,3,6>"),
                                         (700, 4300, "resident_kernel<512,5,4>"), (4500, 200, "resident_kernel<512,1,24>"),
-                                        (5000, 700, "resident_kernel<512,1,24>"), (1300, 4300, "resident_kernel<512,5,6>"), (7000, 300, "resident_kernel<512,1,32>"),
+                                        (5000, 700, "resident_kernel<512,1,24>"), (1300, 4300, "resident_kernel<512,5,6>"), (7000, 300, "resident_kernel<512,1,32>"), (9000, 250, "resident_kernel<512,1,40>"),
+                                        (2600, 2600, "resident_kernel<512,3,12>"), (900, 5800, "resident_kernel<512,6,4>"),
                                         (2100, 2480, "resident_kernel<512,3,9>")])
 def test_resident_variants_match_oracle(nat, ctx, oracle, M, N, kernel):
     """The odd-J and tall variants of the resident kernel, 200 pivots each against the oracle

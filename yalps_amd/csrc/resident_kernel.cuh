@@ -44,7 +44,7 @@ __device__ __forceinline__ void st16_sc1(double *p, double2 v) {
 }
 template <int J>
 __device__ __forceinline__ void ld16_sc1(double2 (&out)[J], const double *base, const int (&ofs)[J]) {
-    static_assert(J >= 1 && J <= 5, "lane units per row");
+    static_assert(J >= 1 && J <= 6, "lane units per row");
     v2f64 t[J];
 #define YLD "global_load_dwordx4 %"
     if constexpr (J == 1) {
@@ -65,11 +65,18 @@ __device__ __forceinline__ void ld16_sc1(double2 (&out)[J], const double *base, 
                      : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3])
                      : "v"(base + ofs[0]), "v"(base + ofs[1]), "v"(base + ofs[2]), "v"(base + ofs[3])
                      : "memory");
-    } else {
+    } else if constexpr (J == 5) {
         asm volatile(YLD "0, %5, off sc1\n\t" YLD "1, %6, off sc1\n\t" YLD "2, %7, off sc1\n\t" YLD "3, %8, off sc1\n\t"
                      YLD "4, %9, off sc1\n\ts_waitcnt vmcnt(0)"
                      : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4])
                      : "v"(base + ofs[0]), "v"(base + ofs[1]), "v"(base + ofs[2]), "v"(base + ofs[3]), "v"(base + ofs[4])
+                     : "memory");
+    } else {
+        asm volatile(YLD "0, %6, off sc1\n\t" YLD "1, %7, off sc1\n\t" YLD "2, %8, off sc1\n\t" YLD "3, %9, off sc1\n\t"
+                     YLD "4, %10, off sc1\n\t" YLD "5, %11, off sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5])
+                     : "v"(base + ofs[0]), "v"(base + ofs[1]), "v"(base + ofs[2]), "v"(base + ofs[3]), "v"(base + ofs[4]),
+                       "v"(base + ofs[5])
                      : "memory");
     }
 #undef YLD
@@ -192,26 +199,19 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
     auto publish = [&]() __attribute__((always_inline)) {
         epoch++;
         const int par = epoch & 1, cg = sh_cg;
-        double2 v[J];
-#pragma unroll
-        for (int j = 0; j < J; j++) v[j] = x[0][j];
-        // v = x[cg] as a chain of register selects.  The empty asm keeps hipcc from rewriting the chain
-        // into a dynamically indexed load, which would move all my rows from registers to scratch.
-#pragma unroll
-        for (int g = 1; g < R; g++) {
-#pragma unroll
-            for (int j = 0; j < J; j++) {
-                double ax = x[g][j].x, ay = x[g][j].y;
-                asm volatile("" : "+v"(ax), "+v"(ay));
-                v[j].x = g == cg ? ax : v[j].x;
-                v[j].y = g == cg ? ay : v[j].y;
-            }
-        }
+        // x[cg] straight from its registers: one uniform branch per slot, the slot index stays a
+        // compile-time constant (a value select over the slots cost 4 R J v_cndmask and, with the copies
+        // hipcc made for it, twice the registers; a runtime index would move the rows to scratch)
         double *dst = d.rc_rows[par] + (size_t)b * pitch;
 #pragma unroll
-        for (int j = 0; j < J; j++) {
-            const int c0 = 2 * (tid + j * T);
-            if (c0 < pitch) st16_sc1(dst + c0, v[j]);
+        for (int g = 0; g < R; g++) {
+            if (g == cg) {
+#pragma unroll
+                for (int j = 0; j < J; j++) {
+                    const int c0 = 2 * (tid + j * T);
+                    if (c0 < pitch) st16_sc1(dst + c0, x[g][j]);
+                }
+            }
         }
         if (tid == cg) st_sc1(d.rc_key[par] + b, my_rhs); // the candidate row's RHS entry (lane cg)
         if (tid == 0) // the key travels next to the flag: one 16-byte record per workgroup

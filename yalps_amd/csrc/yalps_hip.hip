@@ -87,15 +87,15 @@ const RVariant kResident[] = {
     // the fewest row registers J * R; J = 3 / 5 keep 1025..1536 / 2049..2560 units out of the next power of two.
     RVARIANT(256, 1, 4), RVARIANT(256, 1, 9), RVARIANT(256, 1, 16),
     RVARIANT(256, 2, 4), RVARIANT(256, 2, 9),
-    // (no variant may need AGPRs: <256,1,32> (374 registers) left its last row slots unwritten on the
-    // GPU; tests/test_cabi_symbols.py checks the register counts of the built code object)
-    RVARIANT(512, 1, 24), RVARIANT(512, 1, 32), // tall and narrow: 17..32 rows per workgroup
-    RVARIANT(512, 2, 4), RVARIANT(512, 2, 6), RVARIANT(512, 2, 9), RVARIANT(512, 2, 16),
-    RVARIANT(512, 3, 4), RVARIANT(512, 3, 6), RVARIANT(512, 3, 9), // (<512,3,12> spills 450 B: 34 us/pivot at 2561^2, wide_kernel 27)
+    RVARIANT(512, 1, 24), RVARIANT(512, 1, 32), RVARIANT(512, 1, 40), // tall and narrow: 17..40 rows per workgroup
+    RVARIANT(512, 2, 4), RVARIANT(512, 2, 6), RVARIANT(512, 2, 9), RVARIANT(512, 2, 12), RVARIANT(512, 2, 16),
+    RVARIANT(512, 3, 4), RVARIANT(512, 3, 6), RVARIANT(512, 3, 9), RVARIANT(512, 3, 12),
     RVARIANT(512, 4, 4), RVARIANT(512, 4, 6), RVARIANT(512, 4, 9),
     RVARIANT(512, 5, 4), RVARIANT(512, 5, 6),
-    // (<512,2,16>, <512,4,6> and <512,4,9> spill a little at the 256-VGPR cap of an 8-wave workgroup; they
-    // still beat streaming)
+    RVARIANT(512, 6, 4),
+    // (no variant may need AGPRs -- <256,1,32> (374 registers) left its last row slots unwritten on the
+    // GPU -- or more than a few bytes of scratch; tests/test_cabi_symbols.py checks the register counts of
+    // the built code object)
 };
 #undef RVARIANT
 constexpr int RESIDENT_CHUNK = 4096; // pivots per launch of the resident kernel (bounds its run time)
