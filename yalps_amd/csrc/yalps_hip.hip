@@ -93,6 +93,7 @@ const RVariant kResident[] = {
     RVARIANT(512, 4, 4), RVARIANT(512, 4, 6), RVARIANT(512, 4, 9),
     RVARIANT(512, 5, 4), RVARIANT(512, 5, 6),
     RVARIANT(512, 6, 4),
+    // (<1024,1,9> fits its 128 VGPRs now but is no faster at 2049^2: 6.94 against 6.82 us/pivot)
     // (no variant may need AGPRs -- <256,1,32> (374 registers) left its last row slots unwritten on the
     // GPU -- or more than a few bytes of scratch; tests/test_cabi_symbols.py checks the register counts of
     // the built code object)
@@ -440,9 +441,11 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
     if (t->nb <= ctx->num_cus) {
         // (16 waves per CU were tried for 2049^2: <1024,1,9> spills at the 128-VGPR cap and its barriers
         // cost more: 92 K pivots/s against 144 K for <512,2,9>)
-        int best = INT_MAX;
+        int best = INT_MAX, fT = 0, fJ = 0, fR = 0;
+        if (const char *force = std::getenv("YALPS_HIP_RVARIANT")) std::sscanf(force, "%d,%d,%d", &fT, &fJ, &fR);
         for (const RVariant &v : kResident) {
             if (v.T * v.J < units || v.R < rows_per_block) continue;
+            if (fT && (v.T != fT || v.J != fJ || v.R != fR)) continue; // experiments: YALPS_HIP_RVARIANT=T,J,R
             const int regs = v.J * v.R * 1024 + v.T; // fewest row registers, then fewest waves
             if (regs < best) {
                 best = regs;
