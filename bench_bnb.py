@@ -9,6 +9,10 @@ is solved at the root on the GPU; a breadth-first expansion on the most fraction
   (a) as one batch (yalps_batch_solve: one workgroup per node, root resident, cuts applied on device),
   (b) one at a time through the drop-in call (applyCuts on the host, upload, solve, download), on a sample,
 and a sample of nodes is checked bit for bit against the CPU oracle.  Prints one JSON line.
+
+Under torch.distributed.run (--gpus N, one process per GPU) the node queue is dealt round-robin to the
+ranks -- nodes are independent given the root, so there is NO data-path collective; the
+group only carries the barriers and the max-over-ranks time, and `value` is the whole-job rate.
 """
 import argparse
 import json
@@ -30,7 +34,23 @@ def main():
     ap.add_argument("--nodes", type=int, default=1024)
     ap.add_argument("--seq-sample", type=int, default=128)
     ap.add_argument("--check", type=int, default=32)
+    ap.add_argument("--gpus", type=int, default=1)
     args = ap.parse_args()
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        ndev = torch.cuda.device_count()
+        device = int(os.environ.get("LOCAL_RANK", "0")) % max(ndev, 1)
+        # (ranks sharing one GPU, as in the tests on a 1-GPU box, cannot use RCCL: gloo carries the barriers)
+        dist.init_process_group("nccl" if ndev >= world else "gloo",
+                                **({"device_id": torch.device("cuda", device)} if ndev >= world else {}))
+    else:
+        device = 0
 
     from tests import _oracle
     from yalps_amd import _native, branch_and_cut as BC
@@ -46,7 +66,7 @@ def main():
     ints = list(range(1, N + 1))
     max_cuts = 24
 
-    ctx = _native.Context(0)
+    ctx = _native.Context(device)
     batch = _native.NodeBatch(ctx, w, h, max_cuts, args.nodes)
     batch.set_root(m, pos, var)
 
@@ -69,12 +89,26 @@ def main():
                     lower = tuple(c for c in cuts if not (c[1] == variable and c[0] > 0)) + ((1, variable, float(math.floor(value))),)
                     frontier += [upper, lower]
     nodes = nodes[: args.nodes]
+    all_nodes = len(nodes)
+    nodes = nodes[rank::world]  # this rank's share of the queue (every rank built the same queue)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
 
     # (a) one batch
     batch.solve(nodes, 1e-8, 8192)  # warm-up
+    barrier()
     t0 = time.perf_counter()
     sts, ress, pivs, heights, gpu_ms = batch.solve(nodes, 1e-8, 8192)
     wall_batch = time.perf_counter() - t0
+    barrier()
+    if dist is not None:
+        import torch
+        tm = torch.tensor([wall_batch, gpu_ms], dtype=torch.float64)
+        tm = tm.cuda() if dist.get_backend() == "nccl" else tm
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        wall_batch, gpu_ms = float(tm[0]), float(tm[1])
 
     # (b) one node at a time through the drop-in (host applyCuts + upload + solve + download)
     k = min(args.seq_sample, len(nodes))
@@ -106,18 +140,24 @@ def main():
     batch.close()
     ctx.close()
 
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        return
     total_piv = int(pivs.sum())
     bytes_alg = sum(16 * int(heights[i]) * w * int(pivs[i]) for i in range(len(nodes)))
     print(json.dumps({
-        "metric": "branch-and-cut nodes/sec (batched node LPs, 1 MI355X)", "value": len(nodes) / (gpu_ms * 1e-3),
-        "unit": "nodes/s", "n_gpus": 1, "higher_is_better": True, "dtype": "f64", "data": "synthetic",
+        "metric": "branch-and-cut nodes/sec (batched node LPs, %d MI355X)" % world, "value": all_nodes / (gpu_ms * 1e-3),
+        "unit": "nodes/s", "n_gpus": world, "higher_is_better": True, "scaling": "strong", "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%d nodes of a %d-variable x %d-row dense MILP (root tableau %dx%d), <= %d cuts per node"
-                               % (len(nodes), N, Mr, h, w, max_cuts)},
-        "batch": {"gpu_ms": gpu_ms, "wall_ms": 1e3 * wall_batch, "pivots": total_piv, "pivots_per_s": total_piv / (gpu_ms * 1e-3),
-                  "algorithmic_GBps": bytes_alg / (gpu_ms * 1e-3) / 1e9,
+                               % (all_nodes, N, Mr, h, w, max_cuts),
+                   "nodes_per_rank": len(nodes), "collectives_on_the_data_path": 0},
+        "batch": {"gpu_ms": gpu_ms, "wall_ms": 1e3 * wall_batch, "pivots_rank0": total_piv, "pivots_per_s_rank0": total_piv / (gpu_ms * 1e-3),
+                  "algorithmic_GBps_rank0": bytes_alg / (gpu_ms * 1e-3) / 1e9,
                   "status_counts": {s: sts.count(s) for s in sorted(set(sts))}},
         "one_at_a_time": {"nodes": k, "wall_ms": 1e3 * wall_seq, "nodes_per_s": k / wall_seq},
-        "speedup_vs_one_at_a_time": (len(nodes) / wall_batch) / (k / wall_seq),
+        "speedup_vs_one_at_a_time": (all_nodes / wall_batch) / (k / wall_seq),
         "oracle_checked_nodes": checked}))
 
 

@@ -1,5 +1,7 @@
 """Worker of the multi-process row-sharded tests: one rank of a gloo (or nccl) group.
-usage: python -m tests._shard_worker <numpy|hip> <M> <N> <seed> <out.npz>   (RANK/WORLD_SIZE/MASTER_* in env)"""
+usage: python -m tests._shard_worker <numpy|hip> <M> <N> <seed> <out.npz> [max_pivots [digest]]
+(RANK/WORLD_SIZE/MASTER_* in env).  `digest`: instead of the assembled tableau, rank 0 saves the SHA-256 of the
+objective row and of every rank's block of rows (full-size runs: the tableau is 2.1 GB)."""
 import os
 import sys
 
@@ -13,13 +15,17 @@ sys.path.insert(0, ROOT)
 
 def main():
     kind, M, N, seed, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    max_pivots = float(sys.argv[6]) if len(sys.argv) > 6 else float("inf")
+    digest = len(sys.argv) > 7 and sys.argv[7] == "digest"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from tests import _oracle
     from yalps_amd import sharded
     w, h = N + 1, M + 1
     m = _oracle.load().dense_lp(M, N, seed)
-    if seed % 2:  # make some right-hand sides negative so that phase 1 runs too
+    if digest:  # (the full-size test's input: one row "-a x <= -b", so that the first pivot is a phase-1 pivot)
+        m.reshape(h, w)[h // 3] *= -1.0
+    elif seed % 2:  # make some right-hand sides negative so that phase 1 runs too
         m.reshape(h, w)[1::3, 0] *= -0.05
     bounds = sharded.partition(h, world)
     ident = np.arange(w + h, dtype=np.int32)
@@ -30,8 +36,22 @@ def main():
     else:
         ops = sharded.HipShardOps(local, w, bounds, rank, h, ident, ident.copy(), device=0)
     comm = sharded.TorchComm()
-    status, result, pivots = sharded.sharded_simplex(ops, comm, max_pivots=float("inf"), check_every=8)
+    del m
+    status, result, pivots = sharded.sharded_simplex(ops, comm, max_pivots=max_pivots, check_every=8 if max_pivots > 8 else 1)
     lm, pos, var = ops.download()
+    if digest:
+        import hashlib
+        lm = lm.reshape(-1, w)
+        mine = (hashlib.sha256(lm[0].tobytes()).hexdigest(), hashlib.sha256(lm[1:].tobytes()).hexdigest())
+        parts = [None] * world
+        dist.all_gather_object(parts, mine)
+        if rank == 0:
+            np.savez(out, row0=[p[0] for p in parts], blocks=[p[1] for p in parts], bounds=bounds, pos=pos, var=var,
+                     status=status, result=result, pivots=pivots)
+        ops.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     # assemble the global tableau on rank 0
     parts = [None] * world
     dist.all_gather_object(parts, (lm, bounds[rank], bounds[rank + 1]))

@@ -45,3 +45,22 @@ def test_round_to_precision_js_semantics(oracle):
     assert oracle.round_to_precision(-2.5, 1.0) == -2.0
     assert oracle.round_to_precision(0.0, 1e-8) == 0.0
     assert np.isnan(oracle.round_to_precision(1.0, 0.0))
+
+
+NP_RECORDS = [pytest.param(r, id=G.label(r)) for kind in ("cases", "mixed", "dense") for r in G.records(kind)
+              if not r["options"]["checkCycles"] and not (r["kind"] == "dense" and r["M"] > 512)]
+
+
+@pytest.mark.parametrize("rec", NP_RECORDS)
+def test_numpy_restatement_reproduces_reference(oracle, rec):
+    """tests/_np_simplex.py (the vectorised restatement used for the full-size GPU checks) against
+    the reference's golden records: status, result, pivot count, permutations, whole matrix."""
+    from tests import _np_simplex as NP
+    m = G.initial_matrix(rec, oracle)
+    pos, var = G.identity_perms(rec)
+    exp = G.expected(rec)
+    o = G.options(rec)
+    status, result, npiv = NP.simplex(m, rec["width"], rec["height"], pos, var, o["precision"], o["max_pivots"])
+    assert (status, npiv) == (exp["status"], exp["n_pivots"]) and G.same_number(result, exp["result"])
+    assert np.array_equal(pos, exp["pos"]) and np.array_equal(var, exp["var"])
+    assert G.sha256(m) == exp["final_sha256"]
