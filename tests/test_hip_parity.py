@@ -393,3 +393,74 @@ def test_resident_variants_match_oracle(nat, ctx, oracle, M, N, kernel):
     assert (status, npiv) == (est, epiv) and G.same_number(result, eres)
     assert np.array_equal(got.view(np.int64), ref.view(np.int64))
     assert np.array_equal(gpos, rpos) and np.array_equal(gvar, rvar)
+
+
+# ---- persistent in-place kernel (stream_kernel) for tableaux beyond the on-chip size ---------------
+@pytest.mark.parametrize("M,N,pivots", [(2800, 3300, 120), (1400, 8000, 80), (12000, 1500, 60), (11000, 900, 60), (12000, 400, 60)])
+def test_inplace_path_matches_restatement(nat, ctx, M, N, pivots):
+    """Dense tableaux that do not fit the register-resident kernel: `pivots` pivots (phase 1 first)
+    through stream_kernel, against the pinned numpy restatement, bit for bit."""
+    from tests import _np_simplex as NP
+    w, h = N + 1, M + 1
+    m = nat.dense_lp(M, N, 11)
+    m.reshape(h, w)[h // 3] *= -1.0
+    m.reshape(h, w)[5::7, 3::5] = 0.0  # exact zeros: untouched rows / flushed columns
+    pos, var = np.arange(w + h, dtype=np.int32), np.arange(w + h, dtype=np.int32)
+    ref, rpos, rvar = m.copy(), pos.copy(), var.copy()
+    est, eres, epiv = NP.simplex(ref, w, h, rpos, rvar, max_pivots=pivots)
+    t = nat.DeviceTableau(ctx, w, h)
+    try:
+        t.upload(m, h, pos, var)
+        status, result, npiv, _ = t.solve(max_pivots=pivots)
+        info = t.info()
+        got, gpos, gvar = t.download()
+    finally:
+        t.close()
+    assert info["last_path"] == "inplace" and info["resident"].startswith("stream_kernel"), info
+    assert (status, npiv) == (est, epiv) and G.same_number(result, eres)
+    assert np.array_equal(gpos, rpos) and np.array_equal(gvar, rvar)
+    assert np.array_equal(got.view(np.int64), ref.view(np.int64))
+
+
+def test_inplace_path_sparse_netlib_whole_solve(nat, ctx, oracle):
+    """SHIP12L (2197 x 5428, 95 MB, 0.4 % of the rows touched per pivot): the whole solve in place,
+    every bit of the final tableau against the oracle."""
+    from yalps_amd import mps, model as M
+    b = next(x for x in mps.read_benchmarks(os.path.join(G.GOLDEN, "netlib")) if x["name"] == "SHIP12L")
+    t0 = M.tableau_model(b["model"]).tableau
+    ref, rpos, rvar = t0.matrix.copy(), t0.position_of_variable.copy(), t0.variable_at_position.copy()
+    est, eres, epiv, _ = oracle.simplex(ref, t0.width, t0.height, rpos, rvar, max_pivots=np.inf)
+    t = nat.DeviceTableau(ctx, t0.width, t0.height)
+    try:
+        t.upload(t0.matrix, t0.height, t0.position_of_variable, t0.variable_at_position)
+        status, result, npiv, _ = t.solve(max_pivots=np.inf)
+        assert t.info()["last_path"] == "inplace"
+        got, gpos, gvar = t.download()
+    finally:
+        t.close()
+    assert (status, npiv) == (est, epiv) and G.same_number(result, eres)
+    assert np.array_equal(gpos, rpos) and np.array_equal(gvar, rvar)
+    assert np.array_equal(got.view(np.int64), ref.view(np.int64))
+
+
+def test_inplace_fallback_restores_the_tableau(oracle):
+    """A failed hand-off leaves the in-place tableau half updated: the host restores the copy it made before
+    the launch and continues with the launch-per-pivot kernels (forced after two chunks of 30 pivots)."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "from tests import _np_simplex as NP\n"
+        "from yalps_amd import _native as n\n"
+        "M, N = 2800, 3300; w, h = N + 1, M + 1\n"
+        "m = n.dense_lp(M, N, 3); pos = np.arange(w + h, dtype=np.int32); var = pos.copy()\n"
+        "ref, rp, rv = m.copy(), pos.copy(), var.copy(); e = NP.simplex(ref, w, h, rp, rv, max_pivots=100)\n"
+        "ctx = n.Context(0); t = n.DeviceTableau(ctx, w, h); t.upload(m, h, pos, var)\n"
+        "st, res, piv, _ = t.solve(max_pivots=100); info = t.info(); gm, gp, gv = t.download()\n"
+        "assert info['last_path'] == 'inplace+streaming', info\n"
+        "assert (st, piv) == (e[0], e[2]), (st, piv, e)\n"
+        "assert np.array_equal(gm.view(np.int64), ref.view(np.int64)) and np.array_equal(gp, rp) and np.array_equal(gv, rv)\n"
+        "print('ok')\n" % ROOT)
+    env = dict(os.environ, YALPS_HIP_RESIDENT_CHUNK="30", YALPS_HIP_RESIDENT_FAULT="2")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr

@@ -44,8 +44,20 @@ __device__ __forceinline__ void st16_sc1(double *p, double2 v) {
 }
 template <int J>
 __device__ __forceinline__ void ld16_sc1(double2 (&out)[J], const double *base, const int (&ofs)[J]) {
-    static_assert(J >= 1 && J <= 6, "lane units per row");
-    v2f64 t[J];
+    static_assert((J >= 1 && J <= 6) || J == 8, "lane units per row");
+    if constexpr (J == 8) { // two groups of four
+        double2 lo[4], hi[4];
+        const int olo[4] = {ofs[0], ofs[1], ofs[2], ofs[3]}, ohi[4] = {ofs[4], ofs[5], ofs[6], ofs[7]};
+        ld16_sc1<4>(lo, base, olo);
+        ld16_sc1<4>(hi, base, ohi);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            out[j] = lo[j];
+            out[4 + j] = hi[j];
+        }
+        return;
+    }
+    v2f64 t[J > 6 ? 1 : J];
 #define YLD "global_load_dwordx4 %"
     if constexpr (J == 1) {
         asm volatile(YLD "0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(t[0]) : "v"(base + ofs[0]) : "memory");

@@ -10,6 +10,7 @@
 //                        ping-ponged in HBM; also DECIDE/APPLY for checkCycles
 //   wide_kernel.cuh      streaming for tableaux too wide / tall for register batches (pivot row in LDS)
 //   shard_kernels.cuh    row-sharded solve across GPUs: per-rank select kernel (+ MODE_SHARD above)
+//   stream_kernel.cuh    persistent in-place pivot loop for tableaux beyond the on-chip size
 //   wg_simplex.cuh       the whole simplex loop by one workgroup; small_kernel (tableau in LDS)
 //   batch_kernel.cuh     batched branch-and-cut nodes, one workgroup per node
 // Host side here: contexts, tableaux (HBM layout, upload/download), the solve drivers (resident
@@ -45,6 +46,7 @@ namespace {
 #include "shard_kernels.cuh"
 #include "assemble_kernels.cuh"
 #include "resident_kernel.cuh"
+#include "stream_kernel.cuh"
 #include "wg_simplex.cuh"
 #include "batch_kernel.cuh"
 
@@ -90,15 +92,22 @@ const RVariant kResident[] = {
     RVARIANT(512, 1, 24), RVARIANT(512, 1, 32), RVARIANT(512, 1, 40), // tall and narrow: 17..40 rows per workgroup
     RVARIANT(512, 2, 4), RVARIANT(512, 2, 6), RVARIANT(512, 2, 9), RVARIANT(512, 2, 12), RVARIANT(512, 2, 16),
     RVARIANT(512, 3, 4), RVARIANT(512, 3, 6), RVARIANT(512, 3, 9), RVARIANT(512, 3, 12),
-    RVARIANT(512, 4, 4), RVARIANT(512, 4, 6), RVARIANT(512, 4, 9),
+    RVARIANT(512, 4, 4), RVARIANT(512, 4, 6), RVARIANT(512, 4, 8), // (<512,4,9> spills one VGPR on top of 119 SGPRs)
     RVARIANT(512, 5, 4), RVARIANT(512, 5, 6),
     RVARIANT(512, 6, 4),
     // (<1024,1,9> fits its 128 VGPRs now but is no faster at 2049^2: 6.94 against 6.82 us/pivot)
     // (no variant may need AGPRs -- <256,1,32> (374 registers) left its last row slots unwritten on the
-    // GPU -- or more than a few bytes of scratch; tests/test_cabi_symbols.py checks the register counts of
-    // the built code object)
+    // GPU -- or scratch: SGPR spills that end up in scratch computed garbage in stream_kernel<1024,8>;
+    // tests/test_cabi_symbols.py checks the register counts of the built code object)
 };
 #undef RVARIANT
+// stream_kernel<lanes, 16-byte units per lane and row>: same signature as the resident kernel
+const RVariant kStream[] = {
+    {256, 1, 0, stream_kernel<256, 1>},   {256, 2, 0, stream_kernel<256, 2>},   {1024, 1, 0, stream_kernel<1024, 1>},
+    {1024, 2, 0, stream_kernel<1024, 2>}, {1024, 4, 0, stream_kernel<1024, 4>},
+    // (<1024,8> needs 77 VGPR + 118 SGPR spills at the 128-register cap and computed garbage on the GPU: rows wider
+    // than 8193 columns stay with wide_kernel)
+};
 constexpr int RESIDENT_CHUNK = 4096; // pivots per launch of the resident kernel (bounds its run time)
 
 thread_local std::string g_err;
@@ -131,6 +140,7 @@ struct yalps_ctx {
     bool eager = false;
     bool nt_stores = false;
     bool resident = true; // use the on-chip resident kernel when the tableau fits (YALPS_HIP_RESIDENT=0: never)
+    bool inplace = true;  // use the persistent in-place kernel beyond that (YALPS_HIP_INPLACE=0: never)
     int resident_chunk = RESIDENT_CHUNK; // pivots per resident launch (YALPS_HIP_RESIDENT_CHUNK)
     int resident_fault = 0; // test hook: treat the N-th resident launch as failed (YALPS_HIP_RESIDENT_FAULT=N)
     int num_cus = 256;
@@ -152,7 +162,10 @@ struct yalps_tableau {
     int cur = 0; // tableau buffer holding the current tableau
     int shard_parity = 0;
     RVariant rvar{0, 0, 0, nullptr}; // resident kernel variant, fn == nullptr: tableau does not fit
-    int last_path = 0;               // what the last solve ran: 1 resident, 2 streaming, 3 both
+    RVariant svar{0, 0, 0, nullptr}; // stream_kernel variant (persistent, in place)
+    size_t sshmem = 0;
+    bool sattr = false;
+    int last_path = 0;               // what the last solve ran: 1 resident, 2 streaming, 4 small, 8 in place (sums: fallbacks)
     int64_t last_launches = 0;       // kernel launches of the last solve that did work (resident: chunks)
     size_t rshmem = 0;
     int32_t *perm_backup = nullptr; // basis before the resident launch in flight (restored if it fails)
@@ -324,6 +337,7 @@ static int32_t ctx_create(int32_t device, void *ext_stream, bool adopt, yalps_ct
     c->eager = env_int("YALPS_HIP_EAGER", 0) != 0;
     c->nt_stores = env_int("YALPS_HIP_NT", 1) != 0;
     c->resident = env_int("YALPS_HIP_RESIDENT", 1) != 0;
+    c->inplace = env_int("YALPS_HIP_INPLACE", 1) != 0;
     c->resident_chunk = env_int("YALPS_HIP_RESIDENT_CHUNK", RESIDENT_CHUNK);
     if (c->resident_chunk < 1) c->resident_chunk = 1;
     c->resident_fault = env_int("YALPS_HIP_RESIDENT_FAULT", 0);
@@ -453,7 +467,15 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
             }
         }
     }
-    if (t->rvar.fn) {
+    // persistent in-place kernel for what does not fit on chip: lanes x units span the row, the normalised
+    // pivot row + my rows' scalars fit in LDS
+    if (!t->rvar.fn && t->nb <= ctx->num_cus) {
+        for (const RVariant &v : kStream)
+            if (v.T == T && v.J == J) t->svar = v;
+        t->sshmem = sizeof(double) * ((size_t)d.pitch + 3 * (size_t)rows_per_block) + sizeof(int32_t) * (size_t)rows_per_block;
+        if (t->sshmem > 150 * 1024) t->svar.fn = nullptr;
+    }
+    if (t->rvar.fn || t->svar.fn) {
         for (int k = 0; k < 2; k++) {
             HIP_TRY(hipMalloc(&d.rc_rows[k], sizeof(double) * (size_t)t->nb * d.pitch));
             HIP_TRY(hipMalloc(&d.rc_key[k], sizeof(double) * ((size_t)t->nb + 8)));
@@ -508,6 +530,8 @@ int32_t yalps_tableau_info(const yalps_tableau *t, char *buf, int32_t len) {
     char res[96] = "none";
     if (t->rvar.fn)
         std::snprintf(res, sizeof res, "resident_kernel<%d,%d,%d> chunk=%d", t->rvar.T, t->rvar.J, t->rvar.R, RESIDENT_CHUNK);
+    else if (t->svar.fn)
+        std::snprintf(res, sizeof res, "stream_kernel<%d,%d> chunk=%d", t->svar.T, t->svar.J, RESIDENT_CHUNK);
     char str[64];
     if (t->wfn)
         std::snprintf(str, sizeof str, "wide_kernel<%d,%d>", t->var.T, t->var.J);
@@ -515,8 +539,9 @@ int32_t yalps_tableau_info(const yalps_tableau *t, char *buf, int32_t len) {
         std::snprintf(str, sizeof str, "pivot_kernel<%d,%d,%d>", t->var.T, t->var.J, t->var.R);
     std::snprintf(buf, (size_t)len, "streaming=%s workgroups=%d resident=%s last_path=%s last_resident_launches=%lld", str,
                   t->nb, res,
-                  t->last_path == 1 ? "resident" : t->last_path == 2 ? "streaming" : t->last_path == 3 ? "resident+streaming" : t->last_path == 4 ? "small" : "none",
-                  (long long)(t->last_path & 1 ? t->last_launches : 0));
+                  t->last_path == 1 ? "resident" : t->last_path == 2 ? "streaming" : t->last_path == 3 ? "resident+streaming"
+                  : t->last_path == 4 ? "small" : t->last_path == 8 ? "inplace" : t->last_path == 10 ? "inplace+streaming" : "none",
+                  (long long)(t->last_path & 9 ? t->last_launches : 0));
     return 0;
 }
 
@@ -724,14 +749,28 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
     t->last_path = 0;
     t->last_launches = 0;
 
-    // (a) the tableau fits on chip: persistent register-resident kernel, RESIDENT_CHUNK pivots per launch
-    if (!checkCycles && c->resident && t->rvar.fn && t->d.nshards == 1) {
-        const size_t shmem = sizeof(int32_t) * 2 * (size_t)t->perm_len;
-        if (shmem != t->rshmem) {
+    // (a) persistent kernels, one launch = up to `chunk` pivots: the register-resident kernel when the tableau
+    //     fits on chip, else the in-place streaming kernel
+    const bool persistent_ok = !checkCycles && t->d.nshards == 1;
+    const bool use_resident = persistent_ok && c->resident && t->rvar.fn;
+    const bool use_stream = persistent_ok && !use_resident && c->inplace && t->svar.fn;
+    if (use_resident || use_stream) {
+        const bool in_place = use_stream;
+        const RVariant &pv = in_place ? t->svar : t->rvar;
+        const size_t shmem = in_place ? t->sshmem : sizeof(int32_t) * 2 * (size_t)t->perm_len;
+        if (in_place ? !t->sattr : shmem != t->rshmem) {
             if (shmem > 48 * 1024)
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(t->rvar.fn),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-            t->rshmem = shmem;
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pv.fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)shmem));
+            if (in_place)
+                t->sattr = true;
+            else
+                t->rshmem = shmem;
+        }
+        int chunk = c->resident_chunk;
+        if (in_place) { // bound a launch to ~0.25 s: a pivot streams at most the whole tableau (~6 TB/s), never under ~8 us
+            const double us = std::max(8.0, 16.0 * (double)t->height * t->d.w / 6e6);
+            chunk = (int)std::min<double>(chunk, std::max(64.0, 250000.0 / us));
         }
         int parity = 0;
         int32_t *herr = reinterpret_cast<int32_t *>(&t->host_state[3]); // pinned scratch
@@ -739,7 +778,7 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
             for (int k = 0; k < 2; k++)
                 HIP_TRY(hipMemsetAsync(t->d.rc_flag[k], 0, sizeof(unsigned long long) * 2 * (size_t)t->nb, s));
             HIP_TRY(hipMemsetAsync(t->d.rc_err, 0, sizeof(int32_t), s));
-            // the kernel rewrites the basis in place on exit: keep the old one until the launch is known good
+            // the kernel rewrites the basis (and, in place, the tableau): keep the old ones until the launch is known good
             if (t->perm_backup_len < 2 * t->perm_len) {
                 if (t->perm_backup) HIP_TRY(hipFree(t->perm_backup));
                 HIP_TRY(hipMalloc(&t->perm_backup, sizeof(int32_t) * 2 * (size_t)t->perm_len));
@@ -748,23 +787,38 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
             HIP_TRY(hipMemcpyAsync(t->perm_backup, t->d.var, sizeof(int32_t) * (size_t)t->perm_len, hipMemcpyDeviceToDevice, s));
             HIP_TRY(hipMemcpyAsync(t->perm_backup + t->perm_len, t->d.pos, sizeof(int32_t) * (size_t)t->perm_len,
                                    hipMemcpyDeviceToDevice, s));
-            t->rvar.fn<<<dim3(t->nb), dim3(t->rvar.T), shmem, s>>>(t->d, parity, c->resident_chunk);
-            t->last_path |= 1;
+            if (in_place) {
+                const Desc &d = t->d;
+                HIP_TRY(hipMemcpyAsync(d.mat[t->cur ^ 1], d.mat[t->cur], sizeof(double) * (size_t)d.pitch * t->height,
+                                       hipMemcpyDeviceToDevice, s));
+                HIP_TRY(hipMemcpyAsync(d.rhs[t->cur ^ 1], d.rhs[t->cur], sizeof(double) * (size_t)t->height,
+                                       hipMemcpyDeviceToDevice, s));
+            }
+            pv.fn<<<dim3(t->nb), dim3(pv.T), shmem, s>>>(t->d, parity, chunk);
+            t->last_path |= in_place ? 8 : 1;
             t->last_launches++;
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(herr, t->d.rc_err, sizeof(int32_t), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipMemcpyAsync(&t->host_state[1], t->d.st + (parity ^ 1), sizeof(YState), hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
+            if (std::getenv("YALPS_HIP_DEBUG")) {
+                const YState &hs = t->host_state[1];
+                std::fprintf(stderr, "yalps_hip: persistent launch %lld err=%d status=%d phase=%d iter=%g pivots=%lld result=%g mbuf=%d chunk=%d\n",
+                             (long long)t->last_launches, *herr, hs.status, hs.phase, hs.iter, (long long)hs.pivots, hs.result, hs.mbuf, chunk);
+            }
             if (*herr || (c->resident_fault > 0 && t->last_launches == c->resident_fault)) {
-                // a workgroup gave up waiting (grid not co-resident?): never again on this context;
-                // carry on with the streaming kernel from the last consistent state (st[parity])
-                c->resident = false;
+                // a workgroup gave up waiting (grid not co-resident?): never again on this context; carry on with the
+                // launch-per-pivot kernels from the last consistent state (st[parity]; in place: the copy made above)
+                if (in_place)
+                    c->inplace = false;
+                else
+                    c->resident = false;
                 HIP_TRY(hipMemcpyAsync(t->d.var, t->perm_backup, sizeof(int32_t) * (size_t)t->perm_len, hipMemcpyDeviceToDevice, s));
                 HIP_TRY(hipMemcpyAsync(t->d.pos, t->perm_backup + t->perm_len, sizeof(int32_t) * (size_t)t->perm_len,
                                        hipMemcpyDeviceToDevice, s));
                 YState last;
                 HIP_TRY(hipMemcpy(&last, t->d.st + parity, sizeof(YState), hipMemcpyDeviceToHost));
-                t->cur = last.mbuf;
+                t->cur = in_place ? last.mbuf ^ 1 : last.mbuf;
                 if (t->cur != 0) {
                     const Desc &d = t->d;
                     HIP_TRY(hipMemcpyAsync(d.mat[0], d.mat[1], sizeof(double) * (size_t)d.pitch * t->height,
@@ -785,6 +839,7 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
                 finished = true;
                 break;
             }
+            t->cur = t->host_state[1].mbuf; // (resident launches flip the buffer; in place it stays)
             parity ^= 1;
         }
     }
