@@ -338,6 +338,31 @@ __global__ __launch_bounds__(T) void stream_kernel(Desc d, int parity, int chunk
                 if (pub) st16_sc1(pub + c0, v);
             }
         };
+        // the same for a row whose entries are already in registers (streaming loop below)
+        auto finish_loaded = [&](int i, double2 (&x)[J]) __attribute__((always_inline)) {
+            const double coef = colv[i];
+            const bool is_piv = i == lslot;
+            double *mr = mat + (size_t)(b + NB * i) * pitch;
+            const double nq = -coef / q;
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                const int c0 = 2 * (tid + j * T);
+                if (c0 >= pitch) continue;
+                double2 v;
+                if (is_piv) {
+                    v = pv[j];
+                    if (tid == col_tid && j == col_j) v = with_elem(v, ecol, inv_q); // :25
+                } else { // (every row of the list but the pivot row has |coef| > 1e-16)
+                    v = x[j];
+                    const double px = coef * pv[j].x, py = coef * pv[j].y;
+                    const double nx = v.x - px, ny = v.y - py;
+                    v.x = (nzmask & (1u << (2 * j))) ? nx : v.x;
+                    v.y = (nzmask & (1u << (2 * j + 1))) ? ny : v.y;
+                    if (tid == col_tid && j == col_j) v = with_elem(v, ecol, nq); // :36
+                }
+                *reinterpret_cast<double2 *>(mr + c0) = v;
+            }
+        };
         int cg = -1;
         if (!stop) {
             if (phase == 2) {
@@ -383,7 +408,21 @@ __global__ __launch_bounds__(T) void stream_kernel(Desc d, int parity, int chunk
         }
         __syncthreads();
         const int nt = sh_nt;
-        for (int k = 0; k < nt; k++) finish_row(tlist[k], nullptr);
+        if constexpr (J <= 2) { // two rows in flight per lane (the registers allow it up to J = 2)
+            for (int k = 0; k < nt; k += 2) {
+                const int i0 = tlist[k], i1 = tlist[k + 1 < nt ? k + 1 : k];
+                const double *m0 = mat + (size_t)(b + NB * i0) * pitch, *m1 = mat + (size_t)(b + NB * i1) * pitch;
+                double2 xa[J], xb[J];
+#pragma unroll
+                for (int j = 0; j < J; j++) xa[j] = *reinterpret_cast<const double2 *>(m0 + cofs[j]);
+#pragma unroll
+                for (int j = 0; j < J; j++) xb[j] = *reinterpret_cast<const double2 *>(m1 + cofs[j]);
+                finish_loaded(i0, xa);
+                if (k + 1 < nt) finish_loaded(i1, xb);
+            }
+        } else {
+            for (int k = 0; k < nt; k++) finish_row(tlist[k], nullptr);
+        }
         if (b == 0 && tid == 0) { // basis bookkeeping, :7-12 (off the critical path)
             const int leaving = d.var[w + row], entering = d.var[col];
             d.var[w + row] = entering;
