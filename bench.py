@@ -168,7 +168,8 @@ def main():
         if world == 1:
             info = work.info()
             resident = info["last_path"] == "resident"
-            launches = int(info["last_resident_launches"]) if resident else npiv  # per step
+            inplace = info["last_path"] == "inplace"
+            launches = int(info["last_resident_launches"]) if (resident or inplace) else npiv  # per step
             us_pivot = 1e3 * gpu_ms / pivots
             us_launch = 1e3 * gpu_ms / (launches * args.steps)
             bytes_launch = bpp * npiv / launches
@@ -176,13 +177,15 @@ def main():
             out["roofline"] = {
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
                 "traffic": measured_traffic(args.size, resident, bytes_launch / bpp),
-                "kernel": info["resident"].split(" ")[0] if resident else info["streaming"],
+                "kernel": info["resident"].split(" ")[0] if (resident or inplace) else info["streaming"],
                 "launches_per_step": launches, "avg_us": us_launch, "bytes_per_launch": bytes_launch,
                 "us_per_pivot": us_pivot,
                 "note": ("persistent kernel: one launch = up to %s pivots with the tableau resident in registers; "
                          "algorithmic bytes (SURVEY 8d, 16*h*w per pivot) / HIP-event time. frac > 1 means faster "
                          "than streaming the tableau through HBM could ever be; real HBM traffic is `traffic`."
                          % info.get("chunk", "?")) if resident else
+                        ("persistent in-place kernel: one launch = many pivots, rows streamed from HBM / Infinity Cache; "
+                         "algorithmic bytes (SURVEY 8d) / HIP-event time") if inplace else
                         "one launch = one pivot; HIP events over the timed pivot loops / pivots"}
             work.copy_from(pristine)
             us_apply = work.bench_sweep(h // 2, w // 2, args.sweep_launches)
