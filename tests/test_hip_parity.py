@@ -464,3 +464,38 @@ def test_inplace_fallback_restores_the_tableau(oracle):
     env = dict(os.environ, YALPS_HIP_RESIDENT_CHUNK="30", YALPS_HIP_RESIDENT_FAULT="2")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("kind", ["unbounded", "infeasible", "optimal", "optimal-degenerate"])
+def test_inplace_path_terminal_statuses(nat, ctx, kind):
+    """stream_kernel's exits other than the pivot budget, on a tall narrow LP (11001 x 61: beyond the resident
+    variants) solved to the end: unbounded after 124 pivots (result = the column), infeasible after 41
+    phase-1 pivots, optimal, and optimal with every 10th right-hand side zero (ties, ratios <= precision)."""
+    from tests import _np_simplex as NP
+    M, N = 11000, 60
+    w, h = N + 1, M + 1
+    m = nat.dense_lp(M, N, 21)
+    A = m.reshape(h, w)
+    if kind == "unbounded":
+        A[0, 7] = 0.9          # a good reduced cost ...
+        A[1:, 7] = -A[1:, 7]   # ... on a column nothing bounds
+    elif kind == "infeasible":
+        A[h // 2] = -A[h // 2]  # "a x >= 1e6" against thousands of rows "a' x <= ~20"
+        A[h // 2, 0] = -1e6
+    elif kind == "optimal-degenerate":
+        A[1::10, 0] = 0.0
+    pos, var = np.arange(w + h, dtype=np.int32), np.arange(w + h, dtype=np.int32)
+    ref, rpos, rvar = m.copy(), pos.copy(), var.copy()
+    est, eres, epiv = NP.simplex(ref, w, h, rpos, rvar, max_pivots=np.inf)
+    assert est == kind.split("-")[0] and (epiv > 20 or kind == "optimal-degenerate"), (est, epiv)
+    t = nat.DeviceTableau(ctx, w, h)
+    try:
+        t.upload(m, h, pos, var)
+        status, result, npiv, _ = t.solve(max_pivots=np.inf)
+        assert t.info()["last_path"] == "inplace", t.info()
+        got, gpos, gvar = t.download()
+    finally:
+        t.close()
+    assert (status, npiv) == (est, epiv) and G.same_number(result, eres)
+    assert np.array_equal(gpos, rpos) and np.array_equal(gvar, rvar)
+    assert np.array_equal(got.view(np.int64), ref.view(np.int64))
