@@ -152,7 +152,7 @@ __global__ __launch_bounds__(T) void stream_kernel(Desc d, int parity, int chunk
     // entries of my rows in column la, as the rows are now -> lav[]
     auto column_la = [&]() __attribute__((always_inline)) {
         if (la > 0)
-            for (int i = tid; i < my_rows; i += T) lav[i] = mat[(size_t)(b + NB * i) * pitch + la - 1];
+            for (int i = tid; i < my_rows; i += T) lav[i] = ld_sc1(mat + (size_t)(b + NB * i) * pitch + la - 1);
         __syncthreads();
     };
     int done = 0, term = RUNNING;
@@ -254,7 +254,8 @@ __global__ __launch_bounds__(T) void stream_kernel(Desc d, int parity, int chunk
         const int colx = col - 1, ucol = colx >> 1, ecol = colx & 1, col_tid = ucol % T, col_j = ucol / T;
         // pivot-column entries of my rows (gather; my own rows, complete since my last barrier), the
         // objective row's entry and the quotient (from the lane that holds that column)
-        for (int i = tid; i < my_rows; i += T) colv[i] = mat[(size_t)(b + NB * i) * pitch + colx];
+        // (sc1 loads: other waves of this workgroup stored these rows last pivot; read them at L2, not from a vector-L1 line)
+        for (int i = tid; i < my_rows; i += T) colv[i] = ld_sc1(mat + (size_t)(b + NB * i) * pitch + colx);
         if (tid == col_tid) {
 #pragma unroll
             for (int j = 0; j < J; j++)
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(T) void stream_kernel(Desc d, int parity, int chunk
                 const double p = prow[lax]; // normalised pivot-row entry of column la, or FLUSHED
                 const bool pnz = (unsigned long long)__double_as_longlong(p) != FLUSHED;
                 for (int i = tid; i < my_rows; i += T) {
-                    double v = mat[(size_t)(b + NB * i) * pitch + lax];
+                    double v = ld_sc1(mat + (size_t)(b + NB * i) * pitch + lax);
                     const double coef = colv[i];
                     if (i == lslot)
                         v = la == col ? inv_q : (pnz ? p : 0.0);
