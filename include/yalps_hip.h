@@ -108,6 +108,12 @@ int32_t yalps_tableau_download(yalps_tableau *t, double *matrix, int32_t *positi
 int32_t yalps_tableau_download_rhs(yalps_tableau *t, double *col0);
 /* HBM -> HBM copy of matrix + permutations + height (same width; dst capacity >= src height). */
 int32_t yalps_tableau_copy(yalps_tableau *dst, const yalps_tableau *src);
+/* applyCuts (src/branchAndCut.ts:22-61) on the device: dst = root's tableau (HBM -> HBM) + one row per cut
+ * (sign, variable, value), with the new slack variables appended to both permutations.  `root` holds the root's
+ * OPTIMAL tableau (after its own solve) and is left untouched; dst needs capacity for root height + ncuts rows.
+ * A branch-and-cut node then costs no PCIe traffic beyond its cuts, column 0 and the permutations. */
+int32_t yalps_tableau_apply_cuts(yalps_tableau *dst, const yalps_tableau *root, int32_t ncuts,
+                                 const int32_t *cut_sign, const int32_t *cut_variable, const double *cut_value);
 int32_t yalps_tableau_height(const yalps_tableau *t);
 /* Which kernels this tableau uses and which path the last solve took (text, for benchmarks). */
 int32_t yalps_tableau_info(const yalps_tableau *t, char *buf, int32_t len);

@@ -94,8 +94,54 @@ def test_batched_solve_equals_sequential(nat, name):
         pytest.skip("checkCycles uses the one-node-at-a-time path")
     stats = {}
     a = S.solve(case["model"], case["options"], node_batch=32, stats=stats)
-    b = S.solve(case["model"], case["options"])
+    b = S.solve(case["model"], case["options"], device_nodes=False)
     assert a["status"] == b["status"] and G.same_number(a["result"], b["result"]) and a["variables"] == b["variables"]
     assert K.valid_solution_and_status(a, case["expected"], case["model"], case["options"])
-    if stats:
+    if "nodes_used" in stats:  # (roots above 4 MB take the device-resident one-node-at-a-time path instead)
         assert stats["nodes_used"] <= stats["nodes_evaluated"]
+
+
+# ---- one node at a time with the root resident in HBM (yalps_tableau_apply_cuts) -------------------
+@pytest.mark.parametrize("name", ["Knapsack 1", "Large Farm MIP", "Monster 2"])
+def test_device_apply_cuts_matches_host(nat, oracle, name):
+    """applyCuts on the device (rows built from the root's HBM copy) == the host restatement of
+    src/branchAndCut.ts:22-61, bit for bit: matrix, RHS, both permutations."""
+    from tests.test_host_model import oracle_backend
+    case = K.load(name)
+    tabmod = M.tableau_model(case["model"])
+    t = tabmod.tableau
+    status, result = oracle_backend(oracle)(t, case["options"])
+    assert status == "optimal"
+    nodes = _collect_nodes(oracle, tabmod, result, case["options"], 12)
+    extra = 2 * len(tabmod.integers)
+    ctx = nat.Context(0)
+    root, node = nat.DeviceTableau(ctx, t.width, t.height), nat.DeviceTableau(ctx, t.width, t.height + extra)
+    buf = (np.zeros(t.matrix.size + extra * t.width), np.zeros(t.width + t.height + extra, np.int32),
+           np.zeros(t.width + t.height + extra, np.int32))
+    try:
+        root.upload(t.matrix, t.height, t.position_of_variable, t.variable_at_position)
+        for cuts in nodes:
+            cur = BC.apply_cuts(t, buf, cuts)
+            node.apply_cuts(root, cuts)
+            gm, gpos, gvar = node.download()
+            assert node.height == cur.height
+            assert np.array_equal(gm.view(np.int64), cur.matrix.view(np.int64)), cuts
+            assert np.array_equal(gpos, cur.position_of_variable) and np.array_equal(gvar, cur.variable_at_position)
+    finally:
+        node.close()
+        root.close()
+        ctx.close()
+
+
+@pytest.mark.parametrize("name", INTEGER_CASES)
+def test_device_nodes_solve_equals_sequential(nat, name):
+    """The whole MILP with root and nodes resident in HBM (forced for every integer case, whatever its size)
+    against the reference's flow through the host-array drop-in call."""
+    case = K.load(name)
+    opt = dict(S.default_options)
+    opt.update(case["options"])
+    stats = {}
+    a = S._milp_on_device(M.tableau_model(case["model"], sparse=True), opt, stats)
+    b = S.solve(case["model"], case["options"], device_nodes=False)
+    assert a["status"] == b["status"] and G.same_number(a["result"], b["result"]) and a["variables"] == b["variables"]
+    assert K.valid_solution_and_status(a, case["expected"], case["model"], case["options"])

@@ -22,7 +22,7 @@ SYMBOLS = (
     "yalps_tableau_solve", "yalps_tableau_pivot", "yalps_tableau_bench_sweep", "yalps_dense_lp_f64",
     "yalps_round_to_precision", "yalps_ctx_create_on_stream", "yalps_tableau_set_shard", "yalps_shard_slot_doubles",
     "yalps_shard_begin", "yalps_shard_select", "yalps_shard_apply", "yalps_shard_poll", "yalps_tableau_info",
-    "yalps_tableau_assemble", "yalps_simplex_sparse_f64", "yalps_batch_create", "yalps_batch_destroy", "yalps_batch_set_root", "yalps_batch_solve", "yalps_batch_download",
+    "yalps_tableau_assemble", "yalps_simplex_sparse_f64", "yalps_tableau_apply_cuts", "yalps_batch_create", "yalps_batch_destroy", "yalps_batch_set_root", "yalps_batch_solve", "yalps_batch_download",
 )
 
 
@@ -51,6 +51,8 @@ def lib():
         L.yalps_simplex_sparse_f64.restype = C.c_int32
         L.yalps_simplex_sparse_f64.argtypes = [C.c_int32, C.c_int32, C.c_int64, vp, vp, vp, C.c_double, C.c_double,
                                                C.c_int32, vp, vp, vp, f64p, C.POINTER(C.c_int64)]
+        L.yalps_tableau_apply_cuts.restype = C.c_int32
+        L.yalps_tableau_apply_cuts.argtypes = [vp, vp, C.c_int32, vp, vp, vp]
         L.yalps_tableau_assemble.restype = C.c_int32
         L.yalps_tableau_assemble.argtypes = [vp, C.c_int32, C.c_int64, vp, vp, vp]
         L.yalps_ctx_create.restype = C.c_int32
@@ -207,6 +209,14 @@ class DeviceTableau:
 
     def copy_from(self, other):
         check(lib().yalps_tableau_copy(self.handle, other.handle))
+
+    def apply_cuts(self, root, cuts):
+        """self = root's tableau + one row per cut (sign, variable, value), all on the device (yalps_tableau_apply_cuts)."""
+        sign = np.array([c[0] for c in cuts] or [0], np.int32)
+        var = np.array([c[1] for c in cuts] or [0], np.int32)
+        val = np.array([c[2] for c in cuts] or [0.0], np.float64)
+        check(lib().yalps_tableau_apply_cuts(self.handle, root.handle, len(cuts), sign.ctypes.data, var.ctypes.data,
+                                             val.ctypes.data))
 
     def solve(self, precision=1e-8, max_pivots=8192.0, check_cycles=False):
         """Returns (status, result, n_pivots, gpu_ms)."""

@@ -56,17 +56,24 @@ def apply_cuts(tableau, buf, cuts):
 
 
 def most_fractional_var(tableau, int_vars):
-    """:64-85"""
-    highest, variable, value = 0.0, 0, 0.0
-    for int_var in int_vars:
-        row = int(tableau.position_of_variable[int_var]) - tableau.width
-        if row < 0:
-            continue
-        val = tableau.rhs(row)
-        frac = abs(val - _js_round(val))
-        if frac > highest:
-            highest, variable, value = frac, int_var, val
-    return variable, value, highest
+    """:64-85 (vectorised: the first variable with the strictly largest fractional part)"""
+    if not len(int_vars):
+        return 0, 0.0, 0.0
+    ints = np.asarray(int_vars, np.int64)
+    rows = tableau.position_of_variable[ints].astype(np.int64) - tableau.width
+    basic = rows >= 0
+    if not basic.any():
+        return 0, 0.0, 0.0
+    col0 = tableau.col0 if tableau.col0 is not None else tableau.matrix[::tableau.width]
+    vals = col0[rows[basic]]
+    f = np.floor(vals)
+    with np.errstate(invalid="ignore"):
+        frac = np.abs(vals - np.where(vals - f >= 0.5, f + 1.0, f))  # |val - Math.round(val)|
+    frac = np.where(np.isnan(frac), -1.0, frac)  # (NaN never wins a `>` comparison)
+    k = int(np.argmax(frac))  # first maximum = the reference's strict `>` scan
+    if not frac[k] > 0.0:
+        return 0, 0.0, 0.0
+    return int(ints[basic][k]), float(vals[k]), float(frac[k])
 
 
 def branch_and_cut(simplex, tabmod, init_result, options):
@@ -218,6 +225,67 @@ def branch_and_cut_batched(tabmod, init_result, options, node_batch, stats=None)
     finally:
         batch.close()
         ctx.close()
+
+    unfinished = (timedout or it >= max_iterations) and bool(branches) and best_eval >= optimal_threshold
+    status = "timedout" if unfinished else ("infeasible" if not solution_found else "optimal")
+    return (TableauModel(best_tableau, sign, tabmod.variables, integers), status,
+            best_eval if solution_found else math.nan)
+
+
+def branch_and_cut_device(tabmod, root, node, init_result, options, stats=None):
+    """branchAndCut (:89-176), one node at a time like the reference, but with the root's optimal tableau
+    resident in HBM (`root`, a DeviceTableau) and every node built next to it on the device
+    (yalps_tableau_apply_cuts into `node`): per node only the cuts go up and column 0 + the permutations come
+    back -- what most_fractional_var (:64-85) and solution() read.  `tabmod.tableau` is the root's view
+    (col0 + permutations).  Returns what branch_and_cut returns."""
+    tableau, sign, integers = tabmod.tableau, tabmod.sign, tabmod.integers
+    precision, max_iterations = options["precision"], options["maxIterations"]
+    tolerance, timeout = options["tolerance"], options["timeout"]
+    init_variable, init_value, init_frac = most_fractional_var(tableau, integers)
+    if init_frac <= precision:
+        return tabmod, "optimal", init_result
+
+    branches = []
+    heapq.heappush(branches, _Branch(init_result, [(-1, init_variable, float(math.ceil(init_value)))]))
+    heapq.heappush(branches, _Branch(init_result, [(1, init_variable, float(math.floor(init_value)))]))
+    optimal_threshold = init_result * (1.0 - sign * tolerance)
+    now = lambda: time.time() * 1000.0  # noqa: E731  Date.now()
+    stop_time = timeout + now()
+    timedout = now() >= stop_time
+    solution_found, best_eval, best_tableau, it = False, math.inf, tableau, 0
+    if stats is not None:
+        stats.update(device_nodes=0, pivots=0)
+    while it < max_iterations and branches and best_eval >= optimal_threshold and not timedout:
+        br = heapq.heappop(branches)
+        relaxed_eval, cuts = br.eval, br.cuts
+        if relaxed_eval > best_eval:
+            break
+        node.apply_cuts(root, cuts)
+        status, result, npiv, _ = node.solve(precision, options["maxPivots"], options["checkCycles"])
+        if stats is not None:
+            stats["device_nodes"] += 1
+            stats["pivots"] += npiv
+        if status == "optimal" and result < best_eval:
+            _, pos, var = node.download(matrix=False)
+            current = Tableau(None, tableau.width, node.height, pos, var, node.download_rhs())
+            variable, value, frac = most_fractional_var(current, integers)
+            if frac <= precision:
+                solution_found, best_eval, best_tableau = True, result, current
+            else:
+                cuts_upper, cuts_lower = [], []
+                for cut in cuts:
+                    direction, v = cut[0], cut[1]
+                    if v == variable:
+                        (cuts_lower if direction < 0 else cuts_upper).append(cut)
+                    else:
+                        cuts_upper.append(cut)
+                        cuts_lower.append(cut)
+                cuts_lower.append((1, variable, float(math.floor(value))))
+                cuts_upper.append((-1, variable, float(math.ceil(value))))
+                heapq.heappush(branches, _Branch(result, cuts_upper))
+                heapq.heappush(branches, _Branch(result, cuts_lower))
+        timedout = now() >= stop_time
+        it += 1
 
     unfinished = (timedout or it >= max_iterations) and bool(branches) and best_eval >= optimal_threshold
     status = "timedout" if unfinished else ("infeasible" if not solution_found else "optimal")

@@ -33,3 +33,34 @@ __global__ __launch_bounds__(256) void assemble_scatter_kernel(Desc d, int nnz, 
     else
         d.mat[0][(size_t)r * d.pitch + (c - 1)] = val[i];
 }
+
+// applyCuts (src/branchAndCut.ts:22-61) on the device: node tableau = root optimal tableau (already copied into
+// rows [0, h0) of `dst`) + one row per cut (sign, variable, value); one workgroup per cut.  Reads the root's
+// rows and basis from the root's own buffers.
+__global__ __launch_bounds__(256) void apply_cuts_kernel(Desc dst, const double *__restrict__ root_mat,
+                                                         const double *__restrict__ root_rhs,
+                                                         const int32_t *__restrict__ root_pos, int h0, int ncuts,
+                                                         const int32_t *__restrict__ cut_sign,
+                                                         const int32_t *__restrict__ cut_var,
+                                                         const double *__restrict__ cut_val) {
+    const int i = blockIdx.x, tid = threadIdx.x, w = dst.w, n = dst.n, pitch = dst.pitch;
+    if (i < ncuts) {
+        const double sign = (double)cut_sign[i], value = cut_val[i];
+        const int p = root_pos[cut_var[i]];
+        double *row = dst.mat[0] + (size_t)(h0 + i) * pitch;
+        if (p < w) { // non-basic at the root: sign * x <= sign * value   (:32-35)
+            for (int c = tid; c < pitch; c += 256) row[c] = (c == p - 1) ? sign : 0.0;
+            if (tid == 0) dst.rhs[0][h0 + i] = sign * value;
+        } else { // basic in root row p - w: substitute that row   (:36-42)
+            const double *src = root_mat + (size_t)(p - w) * pitch;
+            for (int c = tid; c < pitch; c += 256) row[c] = c < n ? -sign * src[c] : 0.0;
+            if (tid == 0) dst.rhs[0][h0 + i] = sign * (value - root_rhs[p - w]);
+        }
+    }
+    // :46-52 the new rows' slack variables extend both permutations with the identity (workgroup 0)
+    if (i == 0)
+        for (int k = w + h0 + tid; k < w + h0 + ncuts; k += 256) {
+            dst.pos[k] = k;
+            dst.var[k] = k;
+        }
+}

@@ -664,6 +664,45 @@ int32_t yalps_tableau_copy(yalps_tableau *dst, const yalps_tableau *src) {
     return 0;
 }
 
+int32_t yalps_tableau_apply_cuts(yalps_tableau *dst, const yalps_tableau *root, int32_t ncuts, const int32_t *cut_sign,
+                                 const int32_t *cut_variable, const double *cut_value) {
+    if (!dst || !root || dst == root || ncuts < 0 || (ncuts > 0 && (!cut_sign || !cut_variable || !cut_value)))
+        return fail(YALPS_E_ARG, "yalps_tableau_apply_cuts: bad argument");
+    if (root->height < 1 || dst->d.w != root->d.w || dst->ctx != root->ctx || root->d.nshards > 1 || dst->d.nshards > 1 ||
+        (int64_t)root->height + ncuts > dst->d.hcap)
+        return fail(YALPS_E_ARG, "yalps_tableau_apply_cuts: incompatible tableaux");
+    for (int32_t i = 0; i < ncuts; i++)
+        if (cut_variable[i] < 0 || cut_variable[i] >= root->d.w + root->height)
+            return fail(YALPS_E_ARG, "yalps_tableau_apply_cuts: cut on an unknown variable");
+    int32_t rc = yalps_tableau_copy(dst, root); // rows [0, h0), RHS, both permutations
+    if (rc) return rc;
+    if (ncuts == 0) return 0;
+    HIP_TRY(hipSetDevice(dst->ctx->device));
+    hipStream_t s = dst->ctx->stream;
+    if (ncuts > dst->cells_cap) {
+        if (dst->cells) HIP_TRY(hipFree(dst->cells));
+        dst->cells = nullptr;
+        dst->cells_cap = 0;
+        const int64_t cap = (int64_t)ncuts + 1024;
+        HIP_TRY(hipMalloc(&dst->cells, (size_t)cap * 16));
+        dst->cells_cap = cap;
+    }
+    double *dval = static_cast<double *>(dst->cells);
+    int32_t *dsign = reinterpret_cast<int32_t *>(dval + dst->cells_cap), *dvar = dsign + dst->cells_cap;
+    HIP_TRY(hipMemcpyAsync(dval, cut_value, sizeof(double) * (size_t)ncuts, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(dsign, cut_sign, sizeof(int32_t) * (size_t)ncuts, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(dvar, cut_variable, sizeof(int32_t) * (size_t)ncuts, hipMemcpyHostToDevice, s));
+    const int h0 = root->height;
+    apply_cuts_kernel<<<dim3(ncuts), dim3(256), 0, s>>>(dst->d, root->d.mat[root->cur], root->d.rhs[root->cur], root->d.pos, h0,
+                                                        ncuts, dsign, dvar, dval);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    dst->height = h0 + ncuts;
+    dst->perm_len = dst->d.w + dst->height;
+    dst->d.perm_len = dst->perm_len;
+    return 0;
+}
+
 // One launch of small_kernel on the context's stream and the wait for it; the kernel leaves status /
 // result / pivot count in pinned host memory.
 static int32_t run_small(yalps_ctx *c, SmallDesc sd, int32_t checkCycles, double *result_out, int64_t *pivots_out,

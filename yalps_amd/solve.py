@@ -84,15 +84,49 @@ def solution(tabmod, status, result, options):
     return {"status": status, "result": math.nan, "variables": []}  # infeasible | cycled | timedout w/o result
 
 
-def _solve_with(simplex, model, options=None, node_batch=0, stats=None, sparse=False):
+def _milp_on_device(tabmod, opt, stats=None):
+    """A MILP whose root tableau is too big for the single-workgroup path: the root is assembled (sparse) or
+    uploaded once, solved and KEPT in HBM; branch and cut builds every node next to it on the device
+    (branch_and_cut_device).  No tableau ever comes back to the host."""
+    from .branch_and_cut import branch_and_cut_device
+    from .model import Tableau, TableauModel
+    t = tabmod.tableau
+    ctx = _native.Context(0)
+    root = _native.DeviceTableau(ctx, t.width, t.height)
+    node = None
+    try:
+        if t.matrix is None:
+            root.assemble(t.height, *t.cells)
+        else:
+            root.upload(t.matrix, t.height, t.position_of_variable, t.variable_at_position)
+        status, result, _, _ = root.solve(opt["precision"], opt["maxPivots"], opt["checkCycles"])
+        _, pos, var = root.download(matrix=False)
+        view = TableauModel(Tableau(None, t.width, t.height, pos, var, root.download_rhs()), tabmod.sign,
+                            tabmod.variables, tabmod.integers)
+        if status != "optimal":
+            return solution(view, status, result, opt)
+        node = _native.DeviceTableau(ctx, t.width, t.height + 2 * len(tabmod.integers))
+        int_tabmod, int_status, int_result = branch_and_cut_device(view, root, node, result, opt, stats)
+        return solution(int_tabmod, int_status, int_result, opt)
+    finally:
+        if node is not None:
+            node.close()
+        root.close()
+        ctx.close()
+
+
+def _solve_with(simplex, model, options=None, node_batch=0, stats=None, sparse=False, device_nodes=False):
     """src/YALPS.ts:73-92 with the simplex backend as a parameter (tests drive the host logic
     with the CPU oracle through this; the product binds the HIP backend below)."""
     tabmod = tableau_model(model, sparse=sparse)
-    if sparse and (tabmod.integers or 8 * tabmod.tableau.width * tabmod.tableau.height <= SPARSE_MIN_BYTES):
-        tabmod.tableau.dense()  # branch and cut reads the whole root matrix (src/branchAndCut.ts:28,38-41)
     opt = dict(_DEFAULTS)
     if options:
         opt.update({k: v for k, v in options.items() if v is not None})
+    nbytes = 8 * tabmod.tableau.width * tabmod.tableau.height
+    if device_nodes and tabmod.integers and nbytes > SPARSE_MIN_BYTES and not (node_batch > 1 and nbytes <= NODE_BATCH_MAX_BYTES):
+        return _milp_on_device(tabmod, opt, stats)
+    if sparse and (tabmod.integers or nbytes <= SPARSE_MIN_BYTES):
+        tabmod.tableau.dense()  # branch and cut reads the whole root matrix (src/branchAndCut.ts:28,38-41)
     status, result = simplex(tabmod.tableau, opt)
     if not tabmod.integers or status != "optimal":
         return solution(tabmod, status, result, opt)
@@ -107,7 +141,7 @@ def _solve_with(simplex, model, options=None, node_batch=0, stats=None, sparse=F
     return solution(int_tabmod, int_status, int_result, opt)
 
 
-def solve(model, options=None, node_batch=0, stats=None, sparse=True):
+def solve(model, options=None, node_batch=0, stats=None, sparse=True, device_nodes=True):
     """Runs the solver on `model` (see yalps_amd.model) with `options` (keys as in the reference's
     `Options`, src/types.ts:203-265).  Returns {"status", "result", "variables": [(key, value)]}.
 
@@ -117,5 +151,9 @@ def solve(model, options=None, node_batch=0, stats=None, sparse=True):
 
     sparse: a model without integer variables is shipped as the cells tableauModel writes and its
     tableau is assembled in HBM (same tableau, same pivots, 16 B per cell over PCIe instead of
-    8*width*height); False = always the dense host tableau."""
-    return _solve_with(hip_simplex, model, options, node_batch, stats, sparse)
+    8*width*height); False = always the dense host tableau.
+
+    device_nodes: a MILP whose root tableau exceeds the single-workgroup size keeps it in HBM and builds
+    every branch-and-cut node there (yalps_tableau_apply_cuts); False = the reference's flow, every node
+    through the host-array drop-in call."""
+    return _solve_with(hip_simplex, model, options, node_batch, stats, sparse, device_nodes)
