@@ -42,6 +42,12 @@ __device__ __forceinline__ void st16_sc1(double *p, double2 v) {
     v2f64 t = {v.x, v.y};
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
 }
+// one 16-byte record (flag polls: Guideline 16's table lists 16-B sc1 flag stores / polls)
+__device__ __forceinline__ double2 ld16_sc1_one(const void *p) {
+    v2f64 t;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(t) : "v"(p) : "memory");
+    return make_double2(t.x, t.y);
+}
 template <int J>
 __device__ __forceinline__ void ld16_sc1(double2 (&out)[J], const double *base, const int (&ofs)[J]) {
     static_assert((J >= 1 && J <= 6) || J == 8, "lane units per row");
@@ -226,14 +232,11 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
             }
         }
         if (tid == cg) st_sc1(d.rc_key[par] + b, my_rhs); // the candidate row's RHS entry (lane cg)
-        if (tid == 0) // the key travels next to the flag: one 16-byte record per workgroup
-            __hip_atomic_store(d.rc_flag[par] + 2 * b, (unsigned long long)__double_as_longlong(sh_ck), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains ...
-        __syncthreads();                                  // ... before ONE lane raises the flag
-        if (tid == 0)
-            __hip_atomic_store(d.rc_flag[par] + 2 * b + 1, ((unsigned long long)epoch << 32) | (unsigned)sh_ci,
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();                                  // ... before ONE lane raises the flag:
+        if (tid == 0) // ONE 16-byte record {candidate key, epoch << 32 | row}, one store, polled with one 16-byte load
+            st16_sc1(reinterpret_cast<double *>(d.rc_flag[par] + 2 * b),
+                     make_double2(sh_ck, __longlong_as_double((long long)(((unsigned long long)epoch << 32) | (unsigned)sh_ci))));
     };
     // entries of my rows in column la, as the rows are now -> sh_val[0..R)
     auto column_la = [&]() __attribute__((always_inline)) {
@@ -277,12 +280,13 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
         const int par = epoch & 1;
         KI c = {INFINITY, INT_MAX};
         if (tid < NB) {
-            // The key word was stored and drained before the flag word of the same 16-byte record,
-            // and is read AFTER the poll matched (program order of two sc1 loads of one lane).
+            // key and tag are one 16-byte record, written by one store and read by one load
             unsigned long long f = 0;
             unsigned spins = 0;
+            double2 rec;
             for (;;) {
-                f = __hip_atomic_load(d.rc_flag[par] + 2 * tid + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                rec = ld16_sc1_one(d.rc_flag[par] + 2 * tid);
+                f = (unsigned long long)__double_as_longlong(rec.y);
                 if ((unsigned)(f >> 32) == epoch) break;
                 if (++spins > (1u << 22) || __hip_atomic_load(d.rc_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                     sh_fail = 1;
@@ -292,8 +296,7 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
                 __builtin_amdgcn_s_sleep(2);
             }
             c.i = (int)(unsigned)f;
-            c.k = __longlong_as_double((long long)__hip_atomic_load(d.rc_flag[par] + 2 * tid, __ATOMIC_RELAXED,
-                                                                    __HIP_MEMORY_SCOPE_AGENT));
+            c.k = rec.x;
         }
         c = block_argmin<T>(c, sk, si, slot); // (its barrier is the one the polling waves join)
         slot ^= 1;

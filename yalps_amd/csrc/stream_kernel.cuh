@@ -123,16 +123,12 @@ __global__ __launch_bounds__(T) void stream_kernel(Desc d, int parity, int chunk
     unsigned epoch = 0;
     // flag half of the publication (the row data of slot cg has been stored to rc_rows[par] by the caller)
     auto raise_flag = [&](KI cand, int cg, int par) __attribute__((always_inline)) {
-        if (tid == 0) {
-            st_sc1(d.rc_key[par] + b, rhsv[cg]); // the candidate row's RHS entry
-            __hip_atomic_store(d.rc_flag[par] + 2 * b, (unsigned long long)__double_as_longlong(cand.k), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains ...
-        __syncthreads();                                  // ... before ONE lane raises the flag
-        if (tid == 0)
-            __hip_atomic_store(d.rc_flag[par] + 2 * b + 1, ((unsigned long long)epoch << 32) | (unsigned)cand.i,
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) st_sc1(d.rc_key[par] + b, rhsv[cg]); // the candidate row's RHS entry
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains ...
+        __syncthreads();                                    // ... before ONE lane raises the flag:
+        if (tid == 0) // ONE 16-byte record {candidate key, epoch << 32 | row}, one store, polled with one 16-byte load
+            st16_sc1(reinterpret_cast<double *>(d.rc_flag[par] + 2 * b),
+                     make_double2(cand.k, __longlong_as_double((long long)(((unsigned long long)epoch << 32) | (unsigned)cand.i))));
     };
     // publish a candidate whose row is taken from the tableau as it stands
     auto publish_from_tableau = [&](KI cand) __attribute__((always_inline)) {
@@ -183,8 +179,10 @@ __global__ __launch_bounds__(T) void stream_kernel(Desc d, int parity, int chunk
         if (tid < NB) {
             unsigned long long f = 0;
             unsigned spins = 0;
+            double2 rec;
             for (;;) {
-                f = __hip_atomic_load(d.rc_flag[par] + 2 * tid + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                rec = ld16_sc1_one(d.rc_flag[par] + 2 * tid);
+                f = (unsigned long long)__double_as_longlong(rec.y);
                 if ((unsigned)(f >> 32) == epoch) break;
                 if (++spins > (1u << 22) || __hip_atomic_load(d.rc_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                     sh_fail = 1;
@@ -194,8 +192,7 @@ __global__ __launch_bounds__(T) void stream_kernel(Desc d, int parity, int chunk
                 __builtin_amdgcn_s_sleep(2);
             }
             c.i = (int)(unsigned)f;
-            c.k = __longlong_as_double((long long)__hip_atomic_load(d.rc_flag[par] + 2 * tid, __ATOMIC_RELAXED,
-                                                                    __HIP_MEMORY_SCOPE_AGENT));
+            c.k = rec.x;
         }
         c = block_argmin<T>(c, sk, si, slot); // (its barrier is the one the polling waves join)
         slot ^= 1;
