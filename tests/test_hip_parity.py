@@ -336,7 +336,7 @@ def test_golden_cases_without_small_path(nat, oracle, monkeypatch):
             assert G.sha256(gm) == exp["final_sha256"] and np.array_equal(gp, exp["pos"]) and np.array_equal(gv, exp["var"])
     finally:
         c.close()
-    assert "small" not in paths and "resident" in paths, paths
+    assert paths == {"resident"}, paths  # (the checkCycles records too: hasCycle verdicts travel with one more exchange)
 
 
 def test_small_path_check_cycles_history_growth(nat, oracle, monkeypatch):

@@ -73,6 +73,7 @@ struct Desc {
     double *rc_key[2];              // [nb] RHS entry of each workgroup's candidate row
     unsigned long long *rc_flag[2]; // [nb][2] {candidate key bits, (epoch << 32) | global row index}
     int32_t *rc_err;                // set when a workgroup gives up waiting (never expected)
+    unsigned long long *rc_verdict; // [2] checkCycles: workgroup 0's verdict on the pivot of an epoch, (epoch << 32) | cycled
     int32_t perm_len;
 };
 

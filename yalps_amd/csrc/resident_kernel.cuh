@@ -109,7 +109,7 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
     __shared__ double sh_val[R + 2]; // per-row broadcast: pivot-column entry / entering-column entry
     __shared__ double sh_nq[R + 2];  // -coef/quotient per row (:36), for the objective row, 1/quotient (:25)
     __shared__ double sh_ck;         // my candidate for the next exchange: key, row, local slot
-    __shared__ int sh_ci, sh_cg, sh_fail;
+    __shared__ int sh_ci, sh_cg, sh_fail, sh_flag, sh_verdict;
     extern __shared__ int sh_perm[]; // workgroup 0: var[perm_len] then pos[perm_len]
 
     const int tid = threadIdx.x, NB = d.nb, b = blockIdx.x;
@@ -128,6 +128,8 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
     int phase = Sin->phase;
     double iter = Sin->iter;
     int64_t pivots = Sin->pivots;
+    int64_t hist_len = Sin->hist_len; // checkCycles: pivots recorded in the current phase (src/simplex.ts:67,107)
+    const bool check_cycles = C->check_cycles != 0;
     int slot = 0;
 
     int cofs[J];
@@ -305,6 +307,7 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
             if (phase == 1) { // :120 phase 1 is over: same tableau, now the min-ratio exchange
                 phase = 2;
                 iter = 0.0;
+                hist_len = 0;
                 check();
                 if (!stop) {
                     column_la(); // my rows are complete here: their entries of column la
@@ -350,6 +353,41 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
                 continue;
             }
             col = e.i;
+        }
+        if (check_cycles) { // :98,137 hasCycle before the pivot: workgroup 0 (it holds the basis) decides for everybody
+            int cycled = 0;
+            if (b == 0) {
+                const int leaving = sh_perm[w + row], entering = sh_perm[col]; // var[] = sh_perm[0 .. perm_len)
+                cycled = has_cycle(C, hist_len, leaving, entering, &sh_flag) ? 1 : 0;
+                if (tid == 0)
+                    __hip_atomic_store(d.rc_verdict + par, ((unsigned long long)epoch << 32) | (unsigned)cycled,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                if (tid == 0) {
+                    unsigned long long v = 0;
+                    unsigned spins = 0;
+                    for (;;) {
+                        v = __hip_atomic_load(d.rc_verdict + par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((unsigned)(v >> 32) == epoch) break;
+                        if (++spins > (1u << 22) || __hip_atomic_load(d.rc_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                            sh_fail = 1;
+                            __hip_atomic_store(d.rc_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    sh_verdict = (int)(unsigned)v;
+                }
+                __syncthreads();
+                if (sh_fail) return;
+                cycled = sh_verdict;
+            }
+            hist_len += 1;
+            if (cycled) { // ["cycled", NaN]: the tableau stays as it was before this pivot
+                term = YALPS_CYCLED;
+                stop = true;
+                continue;
+            }
         }
         // ---------------- pivot (src/simplex.ts:5-39) on my registers ----------------------------
         // Order: everything the NEXT exchange needs first (objective replica -> la, my rows' entries
@@ -530,7 +568,7 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
             Sout->swap_row = 0;
             Sout->swap_col = 0;
             Sout->pad_ = 0;
-            Sout->hist_len = 0;
+            Sout->hist_len = hist_len;
             Sout->iter = iter;
             Sout->result = term_result;
             Sout->pivots = pivots;

@@ -482,6 +482,7 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
             HIP_TRY(hipMalloc(&d.rc_flag[k], sizeof(unsigned long long) * 2 * (size_t)t->nb));
         }
         HIP_TRY(hipMalloc(&d.rc_err, sizeof(int32_t)));
+        HIP_TRY(hipMalloc(&d.rc_verdict, sizeof(unsigned long long) * 2));
     }
     HIP_TRY(hipHostMalloc(&t->host_state, sizeof(YState) * 4, hipHostMallocDefault));
     for (int k = 0; k < 4; k++) HIP_TRY(hipEventCreateWithFlags(&t->slot_ev[k], hipEventDisableTiming));
@@ -513,7 +514,7 @@ void yalps_tableau_destroy(yalps_tableau *t) {
     }
     Desc &d = t->d;
     void *bufs[] = {d.mat[0], d.mat[1], d.rhs[0], d.rhs[1], d.pos, d.var, d.st, d.cst, d.rc_rows[0], d.rc_rows[1], t->perm_backup,
-                    d.rc_key[0], d.rc_key[1], d.rc_flag[0], d.rc_flag[1], d.rc_err, d.part_ratio[0], d.part_ratio[1], d.part_rhs[0], d.part_rhs[1],
+                    d.rc_key[0], d.rc_key[1], d.rc_flag[0], d.rc_flag[1], d.rc_err, d.rc_verdict, d.part_ratio[0], d.part_ratio[1], d.part_rhs[0], d.part_rhs[1],
                     t->hist[0], t->hist[1], t->cells};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
@@ -790,9 +791,9 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
 
     // (a) persistent kernels, one launch = up to `chunk` pivots: the register-resident kernel when the tableau
     //     fits on chip, else the in-place streaming kernel
-    const bool persistent_ok = !checkCycles && t->d.nshards == 1;
-    const bool use_resident = persistent_ok && c->resident && t->rvar.fn;
-    const bool use_stream = persistent_ok && !use_resident && c->inplace && t->svar.fn;
+    const bool persistent_ok = t->d.nshards == 1;
+    const bool use_resident = persistent_ok && c->resident && t->rvar.fn; // (checkCycles: one more exchange per pivot)
+    const bool use_stream = persistent_ok && !checkCycles && !use_resident && c->inplace && t->svar.fn;
     if (use_resident || use_stream) {
         const bool in_place = use_stream;
         const RVariant &pv = in_place ? t->svar : t->rvar;
@@ -817,6 +818,20 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
             for (int k = 0; k < 2; k++)
                 HIP_TRY(hipMemsetAsync(t->d.rc_flag[k], 0, sizeof(unsigned long long) * 2 * (size_t)t->nb, s));
             HIP_TRY(hipMemsetAsync(t->d.rc_err, 0, sizeof(int32_t), s));
+            HIP_TRY(hipMemsetAsync(t->d.rc_verdict, 0, sizeof(unsigned long long) * 2, s));
+            if (checkCycles) { // room for every pivot this launch can record (no pause inside a persistent launch)
+                const int64_t have = parity == 0 && t->last_launches == 0 ? 0 : t->host_state[1].hist_len;
+                if (have + chunk > t->hist_cap) {
+                    rc = grow_history(t, have + chunk, have);
+                    if (rc) return rc;
+                    YConst hc;
+                    HIP_TRY(hipMemcpy(&hc, t->d.cst, sizeof(YConst), hipMemcpyDeviceToHost));
+                    hc.hist_cap = t->hist_cap;
+                    hc.hist_leaving = t->hist[0];
+                    hc.hist_entering = t->hist[1];
+                    HIP_TRY(hipMemcpy(t->d.cst, &hc, sizeof(YConst), hipMemcpyHostToDevice));
+                }
+            }
             // the kernel rewrites the basis (and, in place, the tableau): keep the old ones until the launch is known good
             if (t->perm_backup_len < 2 * t->perm_len) {
                 if (t->perm_backup) HIP_TRY(hipFree(t->perm_backup));
