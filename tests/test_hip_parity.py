@@ -499,3 +499,33 @@ def test_inplace_path_terminal_statuses(nat, ctx, kind):
     assert (status, npiv) == (est, epiv) and G.same_number(result, eres)
     assert np.array_equal(gpos, rpos) and np.array_equal(gvar, rvar)
     assert np.array_equal(got.view(np.int64), ref.view(np.int64))
+
+
+def test_inplace_path_check_cycles(nat, ctx, oracle):
+    """options.checkCycles through stream_kernel<.., true>: the tall narrow LP solved to optimality with the
+    verdict exchange in every pivot (no cycle), and a Chvatal-style cycling LP embedded in a tall tableau
+    (rows of zeros below it) that must stop "cycled" at the same pivot as the oracle."""
+    M, N = 11000, 60
+    w, h = N + 1, M + 1
+    m = nat.dense_lp(M, N, 21)
+    rec = next(r for r in G.records("cases") if r["name"] == "Chvatal Cycling")
+    small = G.initial_matrix(rec, oracle).reshape(rec["height"], rec["width"])
+    big = np.zeros((11001, rec["width"]))
+    big[:rec["height"]] = small
+    for matrix, width, height, opts in ((m, w, h, dict(precision=1e-8, max_pivots=np.inf, check_cycles=True)),
+                                        (big.reshape(-1), rec["width"], 11001, dict(G.options(rec)))):
+        pos, var = np.arange(width + height, dtype=np.int32), np.arange(width + height, dtype=np.int32)
+        ref, rpos, rvar = matrix.copy(), pos.copy(), var.copy()
+        est, eres, epiv, _ = oracle.simplex(ref, width, height, rpos, rvar, **opts)
+        t = nat.DeviceTableau(ctx, width, height)
+        try:
+            t.upload(matrix, height, pos, var)
+            status, result, npiv, _ = t.solve(**opts)
+            assert t.info()["last_path"] == "inplace", t.info()
+            got, gpos, gvar = t.download()
+        finally:
+            t.close()
+        assert (status, npiv) == (est, epiv) and G.same_number(result, eres)
+        assert np.array_equal(gpos, rpos) and np.array_equal(gvar, rvar)
+        assert np.array_equal(got.view(np.int64), ref.view(np.int64))
+    assert est == "cycled"

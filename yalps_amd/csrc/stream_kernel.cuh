@@ -3,7 +3,7 @@
 #pragma once
 
 // ------------------------------------------------------------------------------------------
-// stream_kernel<T lanes, J units per lane per row>: the whole pivot loop in ONE launch (like
+// stream_kernel<T lanes, J units per lane per row, CHECK = options.checkCycles>: the whole pivot loop in ONE launch (like
 // resident_kernel, same exchange protocol), but the rows stay in HBM / Infinity Cache and are
 // updated IN PLACE by the one workgroup that owns them (rows b, b + NB, ...).  In place is safe
 // here because no workgroup ever reads another workgroup's rows: the pivot row reaches everybody
@@ -26,12 +26,12 @@
 // The launch leaves the tableau in the buffer it found it in.  A hand-off that gives up (never
 // expected) leaves it half updated: the host keeps a copy made before the launch and falls back.
 // ------------------------------------------------------------------------------------------
-template <int T, int J>
+template <int T, int J, bool CHECK>
 __global__ __launch_bounds__(T) void stream_kernel(Desc d, int parity, int chunk) {
     __shared__ double sk[2][16];
     __shared__ int si[2][16];
     __shared__ double sh_q, sh_c0; // quotient; objective-row entry of the pivot column
-    __shared__ int sh_fail, sh_nt;
+    __shared__ int sh_fail, sh_nt, sh_flag, sh_verdict;
     extern __shared__ double sm_dyn[]; // prow[pitch], colv[rpw], lav[rpw], rhsv[rpw], tlist[rpw] (int)
 
     const int tid = threadIdx.x, NB = d.nb, b = blockIdx.x;
@@ -50,6 +50,8 @@ __global__ __launch_bounds__(T) void stream_kernel(Desc d, int parity, int chunk
     int phase = Sin->phase;
     double iter = Sin->iter;
     int64_t pivots = Sin->pivots;
+    int64_t hist_len = Sin->hist_len; // checkCycles: pivots recorded in the current phase
+    constexpr bool check_cycles = CHECK; // (a template parameter: <1024,4> has no register to spare for it)
     int slot = 0;
     const int rpw = (d.hcap + NB - 1) / NB;
     const int my_rows = b < h ? (h - 1 - b) / NB + 1 : 0;
@@ -201,6 +203,7 @@ __global__ __launch_bounds__(T) void stream_kernel(Desc d, int parity, int chunk
             if (phase == 1) { // :120 phase 1 is over: same tableau, now the min-ratio exchange
                 phase = 2;
                 iter = 0.0;
+                hist_len = 0;
                 check();
                 if (!stop) {
                     column_la();
@@ -246,6 +249,42 @@ __global__ __launch_bounds__(T) void stream_kernel(Desc d, int parity, int chunk
                 continue;
             }
             col = e.i;
+        }
+        if (check_cycles) { // :98,137 hasCycle before the pivot: workgroup 0 (it maintains the basis) decides for everybody
+            int cycled = 0;
+            if (b == 0) { // (the basis is updated by my lane 0 behind my own barriers; sc1 loads read it at L2)
+                const int leaving = __hip_atomic_load(d.var + w + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int entering = __hip_atomic_load(d.var + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                cycled = has_cycle(C, hist_len, leaving, entering, &sh_flag) ? 1 : 0;
+                if (tid == 0)
+                    __hip_atomic_store(d.rc_verdict + par, ((unsigned long long)epoch << 32) | (unsigned)cycled,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                if (tid == 0) {
+                    unsigned long long v = 0;
+                    unsigned spins = 0;
+                    for (;;) {
+                        v = __hip_atomic_load(d.rc_verdict + par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((unsigned)(v >> 32) == epoch) break;
+                        if (++spins > (1u << 22) || __hip_atomic_load(d.rc_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                            sh_fail = 1;
+                            __hip_atomic_store(d.rc_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    sh_verdict = (int)(unsigned)v;
+                }
+                __syncthreads();
+                if (sh_fail) return;
+                cycled = sh_verdict;
+            }
+            hist_len += 1;
+            if (cycled) { // ["cycled", NaN]: the tableau stays as it was before this pivot
+                term = YALPS_CYCLED;
+                stop = true;
+                continue;
+            }
         }
         // ---------------- pivot (src/simplex.ts:5-39) ---------------------------------------------
         const int colx = col - 1, ucol = colx >> 1, ecol = colx & 1, col_tid = ucol % T, col_j = ucol / T;
@@ -423,8 +462,8 @@ __global__ __launch_bounds__(T) void stream_kernel(Desc d, int parity, int chunk
         }
         if (b == 0 && tid == 0) { // basis bookkeeping, :7-12 (off the critical path)
             const int leaving = d.var[w + row], entering = d.var[col];
-            d.var[w + row] = entering;
-            d.var[col] = leaving;
+            __hip_atomic_store(d.var + w + row, entering, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(d.var + col, leaving, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             d.pos[leaving] = col;
             d.pos[entering] = w + row;
         }
@@ -449,7 +488,7 @@ __global__ __launch_bounds__(T) void stream_kernel(Desc d, int parity, int chunk
         Sout->swap_row = 0;
         Sout->swap_col = 0;
         Sout->pad_ = 0;
-        Sout->hist_len = 0;
+        Sout->hist_len = hist_len;
         Sout->iter = iter;
         Sout->result = term_result;
         Sout->pivots = pivots;

@@ -103,10 +103,15 @@ const RVariant kResident[] = {
 #undef RVARIANT
 // stream_kernel<lanes, 16-byte units per lane and row>: same signature as the resident kernel
 const RVariant kStream[] = {
-    {256, 1, 0, stream_kernel<256, 1>},   {256, 2, 0, stream_kernel<256, 2>},   {1024, 1, 0, stream_kernel<1024, 1>},
-    {1024, 2, 0, stream_kernel<1024, 2>}, {1024, 4, 0, stream_kernel<1024, 4>},
+    {256, 1, 0, stream_kernel<256, 1, false>},   {256, 2, 0, stream_kernel<256, 2, false>},
+    {1024, 1, 0, stream_kernel<1024, 1, false>}, {1024, 2, 0, stream_kernel<1024, 2, false>},
+    {1024, 4, 0, stream_kernel<1024, 4, false>},
     // (<1024,8> needs 77 VGPR + 118 SGPR spills at the 128-register cap and computed garbage on the GPU: rows wider
     // than 8193 columns stay with wide_kernel)
+};
+const RVariant kStreamCheck[] = { // checkCycles (<1024,4,true> would spill: those tableaux keep DECIDE + APPLY launches)
+    {256, 1, 0, stream_kernel<256, 1, true>},   {256, 2, 0, stream_kernel<256, 2, true>},
+    {1024, 1, 0, stream_kernel<1024, 1, true>}, {1024, 2, 0, stream_kernel<1024, 2, true>},
 };
 constexpr int RESIDENT_CHUNK = 4096; // pivots per launch of the resident kernel (bounds its run time)
 
@@ -163,6 +168,8 @@ struct yalps_tableau {
     int shard_parity = 0;
     RVariant rvar{0, 0, 0, nullptr}; // resident kernel variant, fn == nullptr: tableau does not fit
     RVariant svar{0, 0, 0, nullptr}; // stream_kernel variant (persistent, in place)
+    RVariant svar_check{0, 0, 0, nullptr}; // the same with hasCycle (options.checkCycles)
+    bool sattr_check = false;
     size_t sshmem = 0;
     bool sattr = false;
     int last_path = 0;               // what the last solve ran: 1 resident, 2 streaming, 4 small, 8 in place (sums: fallbacks)
@@ -472,8 +479,10 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
     if (!t->rvar.fn && t->nb <= ctx->num_cus) {
         for (const RVariant &v : kStream)
             if (v.T == T && v.J == J) t->svar = v;
+        for (const RVariant &v : kStreamCheck)
+            if (v.T == T && v.J == J) t->svar_check = v;
         t->sshmem = sizeof(double) * ((size_t)d.pitch + 3 * (size_t)rows_per_block) + sizeof(int32_t) * (size_t)rows_per_block;
-        if (t->sshmem > 150 * 1024) t->svar.fn = nullptr;
+        if (t->sshmem > 150 * 1024) t->svar.fn = t->svar_check.fn = nullptr;
     }
     if (t->rvar.fn || t->svar.fn) {
         for (int k = 0; k < 2; k++) {
@@ -793,17 +802,18 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
     //     fits on chip, else the in-place streaming kernel
     const bool persistent_ok = t->d.nshards == 1;
     const bool use_resident = persistent_ok && c->resident && t->rvar.fn; // (checkCycles: one more exchange per pivot)
-    const bool use_stream = persistent_ok && !checkCycles && !use_resident && c->inplace && t->svar.fn;
+    const bool use_stream = persistent_ok && !use_resident && c->inplace && (checkCycles ? t->svar_check.fn : t->svar.fn);
     if (use_resident || use_stream) {
         const bool in_place = use_stream;
-        const RVariant &pv = in_place ? t->svar : t->rvar;
+        const RVariant &pv = in_place ? (checkCycles ? t->svar_check : t->svar) : t->rvar;
+        bool &sattr = checkCycles ? t->sattr_check : t->sattr;
         const size_t shmem = in_place ? t->sshmem : sizeof(int32_t) * 2 * (size_t)t->perm_len;
-        if (in_place ? !t->sattr : shmem != t->rshmem) {
+        if (in_place ? !sattr : shmem != t->rshmem) {
             if (shmem > 48 * 1024)
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pv.fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)shmem));
             if (in_place)
-                t->sattr = true;
+                sattr = true;
             else
                 t->rshmem = shmem;
         }
