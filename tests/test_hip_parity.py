@@ -529,3 +529,59 @@ def test_inplace_path_check_cycles(nat, ctx, oracle):
         assert np.array_equal(gpos, rpos) and np.array_equal(gvar, rvar)
         assert np.array_equal(got.view(np.int64), ref.view(np.int64))
     assert est == "cycled"
+
+
+@pytest.mark.parametrize("M,N", [(1400, 8000), (300, 16000)])
+def test_check_cycles_on_wide_tableaux_launch_per_pivot(nat, ctx, M, N):
+    """checkCycles where no persistent kernel applies (4098+ columns beyond the on-chip size): DECIDE launches of
+    pivot_kernel<1024,4|8,..> + APPLY launches of wide_kernel, 40 pivots against the numpy restatement (which
+    has no hasCycle: no cycle can close within 40 pivots of these LPs, the check only has to stay silent)."""
+    from tests import _np_simplex as NP
+    w, h = N + 1, M + 1
+    m = nat.dense_lp(M, N, 13)
+    m.reshape(h, w)[h // 3] *= -1.0
+    pos, var = np.arange(w + h, dtype=np.int32), np.arange(w + h, dtype=np.int32)
+    ref, rpos, rvar = m.copy(), pos.copy(), var.copy()
+    est, eres, epiv = NP.simplex(ref, w, h, rpos, rvar, max_pivots=40)
+    t = nat.DeviceTableau(ctx, w, h)
+    try:
+        t.upload(m, h, pos, var)
+        status, result, npiv, _ = t.solve(max_pivots=40, check_cycles=True)
+        assert t.info()["last_path"] == "streaming", t.info()
+        got, gpos, gvar = t.download()
+    finally:
+        t.close()
+    assert (status, npiv) == (est, epiv) and G.same_number(result, eres)
+    assert np.array_equal(gpos, rpos) and np.array_equal(gvar, rvar)
+    assert np.array_equal(got.view(np.int64), ref.view(np.int64))
+
+
+@pytest.mark.parametrize("M,N,kernel", [(4000, 2000, "pivot_kernel<1024,1,16>"), (4000, 500, "pivot_kernel<256,1,16>"),
+                                        (2000, 1000, "pivot_kernel<256,2,8>")])
+def test_launch_per_pivot_fallback_variants(nat, oracle, monkeypatch, M, N, kernel):
+    """The launch-per-pivot kernels a tableau falls back to when the persistent ones are unavailable (context
+    created with YALPS_HIP_RESIDENT=0 / YALPS_HIP_INPLACE=0), including the register-heaviest pivot_kernel
+    variants: 60 pivots against the numpy restatement."""
+    from tests import _np_simplex as NP
+    monkeypatch.setenv("YALPS_HIP_RESIDENT", "0")
+    monkeypatch.setenv("YALPS_HIP_INPLACE", "0")
+    c = nat.Context(0)
+    w, h = N + 1, M + 1
+    m = nat.dense_lp(M, N, 17)
+    m.reshape(h, w)[h // 3] *= -1.0
+    pos, var = np.arange(w + h, dtype=np.int32), np.arange(w + h, dtype=np.int32)
+    ref, rpos, rvar = m.copy(), pos.copy(), var.copy()
+    est, eres, epiv = NP.simplex(ref, w, h, rpos, rvar, max_pivots=60)
+    t = nat.DeviceTableau(c, w, h)
+    try:
+        t.upload(m, h, pos, var)
+        status, result, npiv, _ = t.solve(max_pivots=60)
+        info = t.info()
+        got, gpos, gvar = t.download()
+    finally:
+        t.close()
+        c.close()
+    assert info["last_path"] == "streaming" and info["streaming"] == kernel, info
+    assert (status, npiv) == (est, epiv) and G.same_number(result, eres)
+    assert np.array_equal(gpos, rpos) and np.array_equal(gvar, rvar)
+    assert np.array_equal(got.view(np.int64), ref.view(np.int64))
