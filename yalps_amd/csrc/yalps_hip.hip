@@ -719,7 +719,9 @@ static int32_t run_small(yalps_ctx *c, SmallDesc sd, int32_t checkCycles, double
                          float *gpu_ms_out) {
     hipStream_t s = c->stream;
     const size_t shmem = small_lds_bytes(sd.w, sd.h);
-    const int big = (size_t)sd.h * (size_t)(small_pcols(sd.n) / 2) >= 4096 ? 1 : 0; // 16-byte units to sweep per pivot
+    // 16-byte units to sweep per pivot; 1024 lanes from 1024 units on (36x101: 3.8 -> 3.3 us/pivot, 101x61: 5.1 -> 4.0;
+    // 64 lanes were slower even at 33x33)
+    const int big = (size_t)sd.h * (size_t)(small_pcols(sd.n) / 2) >= 1024 ? 1 : 0;
     const int which = 2 * (checkCycles ? 1 : 0) + big;
     using Fn = void (*)(SmallDesc);
     static const Fn fns[4] = {small_kernel<256, false>, small_kernel<1024, false>, small_kernel<256, true>,
