@@ -585,3 +585,75 @@ def test_launch_per_pivot_fallback_variants(nat, oracle, monkeypatch, M, N, kern
     assert (status, npiv) == (est, epiv) and G.same_number(result, eres)
     assert np.array_equal(gpos, rpos) and np.array_equal(gvar, rvar)
     assert np.array_equal(got.view(np.int64), ref.view(np.int64))
+
+
+def test_golden_cases_through_the_inplace_kernel(nat, oracle, monkeypatch):
+    """Every golden record of the reference (all statuses, checkCycles, odd precisions / maxPivots) through
+    stream_kernel: a context without the single-workgroup and the register-resident paths."""
+    monkeypatch.setenv("YALPS_HIP_SMALL", "0")
+    monkeypatch.setenv("YALPS_HIP_RESIDENT", "0")
+    c = nat.Context(0)
+    paths = set()
+    try:
+        for rec in G.records("cases") + G.records("mixed") + [r for r in G.records("dense") if r["M"] <= 256]:
+            m = G.initial_matrix(rec, oracle, dense_gen=nat.dense_lp)
+            pos, var = G.identity_perms(rec)
+            exp = G.expected(rec)
+            t = nat.DeviceTableau(c, rec["width"], rec["height"])
+            try:
+                t.upload(m, rec["height"], pos, var)
+                st, res, piv, _ = t.solve(**G.options(rec))
+                paths.add(t.info()["last_path"])
+                gm, gp, gv = t.download()
+            finally:
+                t.close()
+            assert (st, piv) == (exp["status"], exp["n_pivots"]) and G.same_number(res, exp["result"]), G.label(rec)
+            assert G.sha256(gm) == exp["final_sha256"] and np.array_equal(gp, exp["pos"]) and np.array_equal(gv, exp["var"])
+    finally:
+        c.close()
+    assert paths == {"inplace"}, paths
+
+
+@pytest.mark.parametrize("path,env", [("small", {}), ("resident", {"YALPS_HIP_SMALL": "0"}),
+                                      ("inplace", {"YALPS_HIP_SMALL": "0", "YALPS_HIP_RESIDENT": "0"}),
+                                      ("streaming", {"YALPS_HIP_SMALL": "0", "YALPS_HIP_RESIDENT": "0", "YALPS_HIP_INPLACE": "0"})])
+def test_degenerate_integer_lps_on_every_path(nat, oracle, monkeypatch, path, env):
+    """Seeded random tableaux with small integer entries (ties everywhere: equal reduced costs, equal ratios,
+    zero right-hand sides, exact zeros) and random options, on each of the four device paths: the lowest-index
+    tie-breaks, the ratio <= precision early exit and the 1e-16 rules must hold across workgroup boundaries."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    c = nat.Context(0)
+    rng = np.random.default_rng(20240607)
+    seen = set()
+    try:
+        for case in range(70 if path == "small" else 84):
+            big = case >= 70  # several rows per workgroup (not for the single-workgroup path: they exceed LDS)
+            h, w = (int(rng.integers(300, 1200)), int(rng.integers(40, 500))) if big else (int(rng.integers(2, 70)), int(rng.integers(2, 90)))
+            m = rng.integers(-3, 4, size=(h, w)).astype(np.float64)
+            m[rng.random((h, w)) < rng.choice([0.0, 0.3, 0.7])] = 0.0
+            m[1:, 0] = rng.integers(-1 if case % 3 == 0 else 0, 5, size=h - 1)  # mostly feasible starts, many zeros
+            m[0, 0] = 0.0
+            if case % 5 == 0:
+                m *= 0.5
+            m = m.reshape(-1)
+            opts = dict(precision=float(rng.choice([1e-8, 1e-6, 1e-12])), max_pivots=float(rng.choice([3000, 7, 60])),  # (finite: these LPs may cycle)
+                        check_cycles=bool(rng.integers(0, 2)))
+            pos, var = np.arange(w + h, dtype=np.int32), np.arange(w + h, dtype=np.int32)
+            ref, rpos, rvar = m.copy(), pos.copy(), var.copy()
+            est, eres, epiv, _ = oracle.simplex(ref, w, h, rpos, rvar, **opts)
+            seen.add(est)
+            t = nat.DeviceTableau(c, w, h)
+            try:
+                t.upload(m, h, pos, var)
+                status, result, npiv, _ = t.solve(**opts)
+                assert t.info()["last_path"] == path, (case, t.info())
+                got, gpos, gvar = t.download()
+            finally:
+                t.close()
+            assert (status, npiv) == (est, epiv) and G.same_number(result, eres), (case, h, w, opts, status, npiv, est, epiv)
+            assert np.array_equal(gpos, rpos) and np.array_equal(gvar, rvar), case
+            assert np.array_equal(got.view(np.int64), ref.view(np.int64)), case
+    finally:
+        c.close()
+    assert {"optimal", "unbounded"} <= seen, seen

@@ -476,7 +476,7 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
     }
     // persistent in-place kernel for what does not fit on chip: lanes x units span the row, the normalised
     // pivot row + my rows' scalars fit in LDS
-    if (!t->rvar.fn && t->nb <= ctx->num_cus) {
+    if (t->nb <= ctx->num_cus) { // (also where a resident variant exists: the fallback order is resident, in place, launches)
         for (const RVariant &v : kStream)
             if (v.T == T && v.J == J) t->svar = v;
         for (const RVariant &v : kStreamCheck)
