@@ -52,3 +52,46 @@ def test_addon_matches_oracle(oracle, shape):
     assert np.array_equal(np.array(res["matrix"]).view(np.int64), ref.view(np.int64))  # JSON round-trips doubles exactly
     assert res["positionOfVariable"] == pos.tolist() and res["variableAtPosition"] == var.tolist()
     assert res["guardsIntact"]  # typed-array views honoured: nothing written outside them
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["Knapsack 1", "Large Farm MIP", "Fancy Stock Cutting Problem"])
+def test_addon_branch_and_cut_exports(oracle, name):
+    """rootSolve / nodeSolve / rootFree under node: the root's optimal tableau stays in HBM, every node is built
+    there from its cut list; root and nodes must equal the oracle on the host-side applyCuts, bit for bit."""
+    from tests import _cases as K
+    from tests.test_batch import _collect_nodes
+    from tests.test_host_model import oracle_backend
+    from yalps_amd import branch_and_cut as BC, model as M
+    case = K.load(name)
+    opt = case["options"]
+    tabmod = M.tableau_model(case["model"])
+    t = tabmod.tableau
+    init = t.matrix.copy()
+    status, result = oracle_backend(oracle)(t, opt)  # t now holds the root's optimal tableau
+    assert status == "optimal"
+    nodes = _collect_nodes(oracle, tabmod, result, opt, 10)
+    extra = 2 * len(tabmod.integers)
+    job = {"matrix": init.tolist(), "width": t.width, "height": t.height, "maxCuts": extra,
+           "options": {"precision": opt["precision"], "maxPivots": opt["maxPivots"], "checkCycles": opt["checkCycles"]},
+           "nodes": [[[int(s), int(v), float(x)] for s, v, x in cuts] for cuts in nodes]}
+    out = subprocess.run(["node", os.path.join(ROOT, "yalps_amd", "napi", "run_nodes.js")], input=json.dumps(job),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert "error" not in res, res
+    assert res["status"] == "optimal" and float(res["result"]) == result
+    f64 = lambda h: np.frombuffer(bytes.fromhex(h), np.float64)  # (hex of the bytes: JSON would turn -0 into 0)
+    assert np.array_equal(f64(res["col0"]).view(np.int64), t.matrix.reshape(t.height, t.width)[:, 0].view(np.int64))
+    assert res["positionOfVariable"] == t.position_of_variable.tolist()
+    buf = (np.zeros(t.matrix.size + extra * t.width), np.zeros(t.width + t.height + extra, np.int32),
+           np.zeros(t.width + t.height + extra, np.int32))
+    for cuts, got in zip(nodes, res["nodes"]):
+        cur = BC.apply_cuts(t, buf, cuts)
+        m, pos, var = cur.matrix.copy(), cur.position_of_variable.copy(), cur.variable_at_position.copy()
+        est, eres, _, _ = oracle.simplex(m, cur.width, cur.height, pos, var, precision=opt["precision"],
+                                         max_pivots=opt["maxPivots"], check_cycles=opt["checkCycles"])
+        assert got["status"] == est and got["height"] == cur.height
+        assert (eres != eres and got["result"] == "NaN") or float(got["result"]) == eres
+        assert np.array_equal(f64(got["col0"]).view(np.int64), m.reshape(cur.height, cur.width)[:, 0].view(np.int64))
+        assert got["positionOfVariable"] == pos.tolist() and got["variableAtPosition"] == var.tolist()
