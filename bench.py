@@ -99,12 +99,20 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # (rehearsal on a box with fewer GPUs than ranks: the ranks share GPU 0 and gloo carries the barriers;
+    #  that is only for checking the multi-rank control flow, never for numbers)
+    rehearsal = world > torch.cuda.device_count()
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     if args.workload == "sharded":
         return bench_sharded(args, torch, dist, rank, local_rank, world)
@@ -145,7 +153,7 @@ def main():
     if seed == 42 and args.size == 2048:  # known answer of the reference
         assert (npiv, result) == (3923, -1022.09813705), (npiv, result)
 
-    tot = torch.tensor([dt, float(pivots)], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([dt, float(pivots)], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
     if dist is not None:
         tmax = tot.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -165,6 +173,8 @@ def main():
                                    "per step (%d pivots on rank 0), one independent LP per GPU" % (M, N, h, w, npiv),
                        "pivots_per_step": npiv, "objective_cell": result},
         }
+        if rehearsal:
+            out["rehearsal"] = "ranks share GPU 0 (fewer GPUs than ranks): control-flow check only"
         if world == 1:
             info = work.info()
             resident = info["last_path"] == "resident"
