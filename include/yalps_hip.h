@@ -106,6 +106,9 @@ int32_t yalps_tableau_download(yalps_tableau *t, double *matrix, int32_t *positi
                                int32_t *variableAtPosition);
 /* HBM -> host, only column 0 (height doubles, contiguous). */
 int32_t yalps_tableau_download_rhs(yalps_tableau *t, double *col0);
+/* HBM -> host, what solution() / mostFractionalVar read: column 0 (height doubles) and both permutations, one wait. */
+int32_t yalps_tableau_download_solution(yalps_tableau *t, double *col0, int32_t *positionOfVariable,
+                                        int32_t *variableAtPosition);
 /* HBM -> HBM copy of matrix + permutations + height (same width; dst capacity >= src height). */
 int32_t yalps_tableau_copy(yalps_tableau *dst, const yalps_tableau *src);
 /* applyCuts (src/branchAndCut.ts:22-61) on the device: dst = root's tableau (HBM -> HBM) + one row per cut

@@ -22,7 +22,7 @@ SYMBOLS = (
     "yalps_tableau_solve", "yalps_tableau_pivot", "yalps_tableau_bench_sweep", "yalps_dense_lp_f64",
     "yalps_round_to_precision", "yalps_ctx_create_on_stream", "yalps_tableau_set_shard", "yalps_shard_slot_doubles",
     "yalps_shard_begin", "yalps_shard_select", "yalps_shard_apply", "yalps_shard_poll", "yalps_tableau_info",
-    "yalps_tableau_assemble", "yalps_simplex_sparse_f64", "yalps_tableau_apply_cuts", "yalps_batch_create", "yalps_batch_destroy", "yalps_batch_set_root", "yalps_batch_solve", "yalps_batch_download",
+    "yalps_tableau_assemble", "yalps_simplex_sparse_f64", "yalps_tableau_apply_cuts", "yalps_tableau_download_solution", "yalps_batch_create", "yalps_batch_destroy", "yalps_batch_set_root", "yalps_batch_solve", "yalps_batch_download",
 )
 
 
@@ -51,6 +51,8 @@ def lib():
         L.yalps_simplex_sparse_f64.restype = C.c_int32
         L.yalps_simplex_sparse_f64.argtypes = [C.c_int32, C.c_int32, C.c_int64, vp, vp, vp, C.c_double, C.c_double,
                                                C.c_int32, vp, vp, vp, f64p, C.POINTER(C.c_int64)]
+        L.yalps_tableau_download_solution.restype = C.c_int32
+        L.yalps_tableau_download_solution.argtypes = [vp, vp, vp, vp]
         L.yalps_tableau_apply_cuts.restype = C.c_int32
         L.yalps_tableau_apply_cuts.argtypes = [vp, vp, C.c_int32, vp, vp, vp]
         L.yalps_tableau_assemble.restype = C.c_int32
@@ -207,6 +209,13 @@ class DeviceTableau:
         check(lib().yalps_tableau_download_rhs(self.handle, col0.ctypes.data))
         return col0
 
+    def download_solution(self, perm_len=None):
+        """(col0, positionOfVariable, variableAtPosition) with one wait (yalps_tableau_download_solution)."""
+        n = perm_len if perm_len is not None else self.width + self.height
+        col0, pos, var = np.empty(self.height, np.float64), np.empty(n, np.int32), np.empty(n, np.int32)
+        check(lib().yalps_tableau_download_solution(self.handle, col0.ctypes.data, pos.ctypes.data, var.ctypes.data))
+        return col0, pos, var
+
     def copy_from(self, other):
         check(lib().yalps_tableau_copy(self.handle, other.handle))
 
@@ -218,11 +227,11 @@ class DeviceTableau:
         check(lib().yalps_tableau_apply_cuts(self.handle, root.handle, len(cuts), sign.ctypes.data, var.ctypes.data,
                                              val.ctypes.data))
 
-    def solve(self, precision=1e-8, max_pivots=8192.0, check_cycles=False):
-        """Returns (status, result, n_pivots, gpu_ms)."""
+    def solve(self, precision=1e-8, max_pivots=8192.0, check_cycles=False, timing=True):
+        """Returns (status, result, n_pivots, gpu_ms); timing=False skips the HIP events (gpu_ms = 0)."""
         res, npiv, ms = C.c_double(), C.c_int64(), C.c_float()
         st = check(lib().yalps_tableau_solve(self.handle, precision, float(max_pivots), int(bool(check_cycles)),
-                                             C.byref(res), C.byref(npiv), C.byref(ms)))
+                                             C.byref(res), C.byref(npiv), C.byref(ms) if timing else None))
         return STATUS[st], res.value, npiv.value, ms.value
 
     def info(self):

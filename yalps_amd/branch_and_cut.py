@@ -261,13 +261,13 @@ def branch_and_cut_device(tabmod, root, node, init_result, options, stats=None):
         if relaxed_eval > best_eval:
             break
         node.apply_cuts(root, cuts)
-        status, result, npiv, _ = node.solve(precision, options["maxPivots"], options["checkCycles"])
+        status, result, npiv, _ = node.solve(precision, options["maxPivots"], options["checkCycles"], timing=False)
         if stats is not None:
             stats["device_nodes"] += 1
             stats["pivots"] += npiv
         if status == "optimal" and result < best_eval:
-            _, pos, var = node.download(matrix=False)
-            current = Tableau(None, tableau.width, node.height, pos, var, node.download_rhs())
+            col0, pos, var = node.download_solution()
+            current = Tableau(None, tableau.width, node.height, pos, var, col0)
             variable, value, frac = most_fractional_var(current, integers)
             if frac <= precision:
                 solution_found, best_eval, best_tableau = True, result, current

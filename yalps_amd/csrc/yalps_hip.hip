@@ -167,6 +167,8 @@ struct yalps_tableau {
     int cur = 0; // tableau buffer holding the current tableau
     int shard_parity = 0;
     RVariant rvar{0, 0, 0, nullptr}; // resident kernel variant, fn == nullptr: tableau does not fit
+    void *rc_sync = nullptr; // flags[2], verdict[2], error word of the persistent kernels (one allocation)
+    size_t rc_sync_bytes = 0;
     RVariant svar{0, 0, 0, nullptr}; // stream_kernel variant (persistent, in place)
     RVariant svar_check{0, 0, 0, nullptr}; // the same with hasCycle (options.checkCycles)
     bool sattr_check = false;
@@ -190,6 +192,7 @@ struct yalps_tableau {
     int32_t *hist[2] = {nullptr, nullptr};
     int64_t hist_cap = 0;
     void *cells = nullptr; // staging of yalps_tableau_assemble: row[] col[] val[] of cells_cap entries
+    std::vector<char> cut_stage; // host side of yalps_tableau_apply_cuts' one packed upload
     int64_t cells_cap = 0;
 };
 
@@ -488,10 +491,16 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
         for (int k = 0; k < 2; k++) {
             HIP_TRY(hipMalloc(&d.rc_rows[k], sizeof(double) * (size_t)t->nb * d.pitch));
             HIP_TRY(hipMalloc(&d.rc_key[k], sizeof(double) * ((size_t)t->nb + 8)));
-            HIP_TRY(hipMalloc(&d.rc_flag[k], sizeof(unsigned long long) * 2 * (size_t)t->nb));
         }
-        HIP_TRY(hipMalloc(&d.rc_err, sizeof(int32_t)));
-        HIP_TRY(hipMalloc(&d.rc_verdict, sizeof(unsigned long long) * 2));
+        // flags of both parities, verdict words and the error word in ONE block: one memset per launch
+        const size_t nflag = 2 * (size_t)t->nb;
+        t->rc_sync_bytes = sizeof(unsigned long long) * (2 * nflag + 2) + 16;
+        HIP_TRY(hipMalloc(&t->rc_sync, t->rc_sync_bytes));
+        unsigned long long *base = static_cast<unsigned long long *>(t->rc_sync);
+        d.rc_flag[0] = base;
+        d.rc_flag[1] = base + nflag;
+        d.rc_verdict = base + 2 * nflag;
+        d.rc_err = reinterpret_cast<int32_t *>(base + 2 * nflag + 2);
     }
     HIP_TRY(hipHostMalloc(&t->host_state, sizeof(YState) * 4, hipHostMallocDefault));
     for (int k = 0; k < 4; k++) HIP_TRY(hipEventCreateWithFlags(&t->slot_ev[k], hipEventDisableTiming));
@@ -523,7 +532,7 @@ void yalps_tableau_destroy(yalps_tableau *t) {
     }
     Desc &d = t->d;
     void *bufs[] = {d.mat[0], d.mat[1], d.rhs[0], d.rhs[1], d.pos, d.var, d.st, d.cst, d.rc_rows[0], d.rc_rows[1], t->perm_backup,
-                    d.rc_key[0], d.rc_key[1], d.rc_flag[0], d.rc_flag[1], d.rc_err, d.rc_verdict, d.part_ratio[0], d.part_ratio[1], d.part_rhs[0], d.part_rhs[1],
+                    d.rc_key[0], d.rc_key[1], t->rc_sync, d.part_ratio[0], d.part_ratio[1], d.part_rhs[0], d.part_rhs[1],
                     t->hist[0], t->hist[1], t->cells};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
@@ -652,6 +661,18 @@ int32_t yalps_tableau_assemble(yalps_tableau *t, int32_t height, int64_t nnz, co
     return 0;
 }
 
+int32_t yalps_tableau_download_solution(yalps_tableau *t, double *col0, int32_t *pos, int32_t *var) {
+    if (!t || !col0 || !pos || !var) return fail(YALPS_E_ARG, "yalps_tableau_download_solution: NULL argument");
+    HIP_TRY(hipSetDevice(t->ctx->device));
+    hipStream_t s = t->ctx->stream;
+    const size_t nperm = sizeof(int32_t) * (size_t)t->perm_len;
+    HIP_TRY(hipMemcpyAsync(col0, t->d.rhs[t->cur], sizeof(double) * (size_t)t->height, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(pos, t->d.pos, nperm, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(var, t->d.var, nperm, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
 int32_t yalps_tableau_copy(yalps_tableau *dst, const yalps_tableau *src) {
     if (!dst || !src) return fail(YALPS_E_ARG, "yalps_tableau_copy: NULL argument");
     if (dst->d.w != src->d.w || dst->d.hcap < src->height || dst->ctx != src->ctx || src->d.nshards > 1 ||
@@ -684,11 +705,25 @@ int32_t yalps_tableau_apply_cuts(yalps_tableau *dst, const yalps_tableau *root, 
     for (int32_t i = 0; i < ncuts; i++)
         if (cut_variable[i] < 0 || cut_variable[i] >= root->d.w + root->height)
             return fail(YALPS_E_ARG, "yalps_tableau_apply_cuts: cut on an unknown variable");
-    int32_t rc = yalps_tableau_copy(dst, root); // rows [0, h0), RHS, both permutations
-    if (rc) return rc;
-    if (ncuts == 0) return 0;
     HIP_TRY(hipSetDevice(dst->ctx->device));
     hipStream_t s = dst->ctx->stream;
+    { // rows [0, h0), RHS, both permutations: HBM -> HBM, in stream order (no host wait in between)
+        dst->cur = 0;
+        HIP_TRY(hipMemcpyAsync(dst->d.mat[0], root->d.mat[root->cur], sizeof(double) * (size_t)root->d.pitch * root->height,
+                               hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(dst->d.rhs[0], root->d.rhs[root->cur], sizeof(double) * (size_t)root->height,
+                               hipMemcpyDeviceToDevice, s));
+        const size_t nperm = sizeof(int32_t) * (size_t)(root->d.w + root->height);
+        HIP_TRY(hipMemcpyAsync(dst->d.pos, root->d.pos, nperm, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(dst->d.var, root->d.var, nperm, hipMemcpyDeviceToDevice, s));
+        dst->height = root->height;
+        dst->perm_len = root->perm_len;
+        dst->d.perm_len = root->perm_len;
+    }
+    if (ncuts == 0) {
+        HIP_TRY(hipStreamSynchronize(s));
+        return 0;
+    }
     if (ncuts > dst->cells_cap) {
         if (dst->cells) HIP_TRY(hipFree(dst->cells));
         dst->cells = nullptr;
@@ -697,11 +732,14 @@ int32_t yalps_tableau_apply_cuts(yalps_tableau *dst, const yalps_tableau *root, 
         HIP_TRY(hipMalloc(&dst->cells, (size_t)cap * 16));
         dst->cells_cap = cap;
     }
+    // the three cut arrays in one upload: value[ncuts] | sign[ncuts] | variable[ncuts]
+    dst->cut_stage.resize((size_t)ncuts * 16);
+    std::memcpy(dst->cut_stage.data(), cut_value, sizeof(double) * (size_t)ncuts);
+    std::memcpy(dst->cut_stage.data() + sizeof(double) * (size_t)ncuts, cut_sign, sizeof(int32_t) * (size_t)ncuts);
+    std::memcpy(dst->cut_stage.data() + 12 * (size_t)ncuts, cut_variable, sizeof(int32_t) * (size_t)ncuts);
     double *dval = static_cast<double *>(dst->cells);
-    int32_t *dsign = reinterpret_cast<int32_t *>(dval + dst->cells_cap), *dvar = dsign + dst->cells_cap;
-    HIP_TRY(hipMemcpyAsync(dval, cut_value, sizeof(double) * (size_t)ncuts, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(dsign, cut_sign, sizeof(int32_t) * (size_t)ncuts, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(dvar, cut_variable, sizeof(int32_t) * (size_t)ncuts, hipMemcpyHostToDevice, s));
+    int32_t *dsign = reinterpret_cast<int32_t *>(dval + ncuts), *dvar = dsign + ncuts;
+    HIP_TRY(hipMemcpyAsync(dval, dst->cut_stage.data(), (size_t)ncuts * 16, hipMemcpyHostToDevice, s));
     const int h0 = root->height;
     apply_cuts_kernel<<<dim3(ncuts), dim3(256), 0, s>>>(dst->d, root->d.mat[root->cur], root->d.rhs[root->cur], root->d.pos, h0,
                                                         ncuts, dsign, dvar, dval);
@@ -793,7 +831,7 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
     const int which = checkCycles ? 1 : 0;
     int rc = init_state(t, precision, maxPivots, checkCycles);
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(c->ev0, s));
+    if (gpu_ms_out) HIP_TRY(hipEventRecord(c->ev0, s));
     YState fin;
     std::memset(&fin, 0, sizeof fin);
     bool finished = false;
@@ -827,10 +865,7 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
         int parity = 0;
         int32_t *herr = reinterpret_cast<int32_t *>(&t->host_state[3]); // pinned scratch
         for (;;) {
-            for (int k = 0; k < 2; k++)
-                HIP_TRY(hipMemsetAsync(t->d.rc_flag[k], 0, sizeof(unsigned long long) * 2 * (size_t)t->nb, s));
-            HIP_TRY(hipMemsetAsync(t->d.rc_err, 0, sizeof(int32_t), s));
-            HIP_TRY(hipMemsetAsync(t->d.rc_verdict, 0, sizeof(unsigned long long) * 2, s));
+            HIP_TRY(hipMemsetAsync(t->rc_sync, 0, t->rc_sync_bytes, s));
             if (checkCycles) { // room for every pivot this launch can record (no pause inside a persistent launch)
                 const int64_t have = parity == 0 && t->last_launches == 0 ? 0 : t->host_state[1].hist_len;
                 if (have + chunk > t->hist_cap) {
@@ -956,8 +991,10 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
             HIP_TRY(hipMemcpy(t->d.st, &now, sizeof(YState), hipMemcpyHostToDevice));
         }
     }
-    HIP_TRY(hipEventRecord(c->ev1, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    if (gpu_ms_out) HIP_TRY(hipEventRecord(c->ev1, s));
+    // (the persistent paths have waited for their last launch; the launch-per-pivot loop may still have a
+    // batch of no-op launches and a state copy in flight)
+    if (gpu_ms_out || (t->last_path & 2)) HIP_TRY(hipStreamSynchronize(s));
     if (gpu_ms_out) HIP_TRY(hipEventElapsedTime(gpu_ms_out, c->ev0, c->ev1));
     t->cur = fin.mbuf;
     if (result_out) *result_out = fin.result;

@@ -100,8 +100,8 @@ def _milp_on_device(tabmod, opt, stats=None):
         else:
             root.upload(t.matrix, t.height, t.position_of_variable, t.variable_at_position)
         status, result, _, _ = root.solve(opt["precision"], opt["maxPivots"], opt["checkCycles"])
-        _, pos, var = root.download(matrix=False)
-        view = TableauModel(Tableau(None, t.width, t.height, pos, var, root.download_rhs()), tabmod.sign,
+        col0, pos, var = root.download_solution()
+        view = TableauModel(Tableau(None, t.width, t.height, pos, var, col0), tabmod.sign,
                             tabmod.variables, tabmod.integers)
         if status != "optimal":
             return solution(view, status, result, opt)
