@@ -186,8 +186,8 @@ def main():
             ach = bytes_launch / (us_launch * 1e-6) / 1e9
             out["roofline"] = {
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-                "traffic": measured_traffic(args.size, resident, bytes_launch / bpp),
-                "kernel": info["resident"].split(" ")[0] if (resident or inplace) else info["streaming"],
+                "traffic": None if inplace else measured_traffic(args.size, resident, bytes_launch / bpp),
+                "kernel": info["resident"].split(" ")[0] if resident else info["inplace"] if inplace else info["streaming"],
                 "launches_per_step": launches, "avg_us": us_launch, "bytes_per_launch": bytes_launch,
                 "us_per_pivot": us_pivot,
                 "note": ("persistent kernel: one launch = up to %s pivots with the tableau resident in registers; "

@@ -416,7 +416,7 @@ def test_inplace_path_matches_restatement(nat, ctx, M, N, pivots):
         got, gpos, gvar = t.download()
     finally:
         t.close()
-    assert info["last_path"] == "inplace" and info["resident"].startswith("stream_kernel"), info
+    assert info["last_path"] == "inplace" and info["inplace"].startswith("stream_kernel"), info
     assert (status, npiv) == (est, epiv) and G.same_number(result, eres)
     assert np.array_equal(gpos, rpos) and np.array_equal(gvar, rvar)
     assert np.array_equal(got.view(np.int64), ref.view(np.int64))

@@ -14,7 +14,7 @@ for b in mps.read_benchmarks(os.path.join(G.GOLDEN, "netlib")):
         st, res, piv, ms = t.solve(precision=b["options"]["precision"], max_pivots=math.inf, check_cycles=b["options"]["checkCycles"])
         best = ms if best is None else min(best, ms)
     info = t.info()
-    kern = {"small": "small_kernel", "resident": info["resident"].split(" ")[0], "inplace": info["resident"].split(" ")[0],
+    kern = {"small": "small_kernel", "resident": info["resident"].split(" ")[0], "inplace": info["inplace"],
             "streaming": info["streaming"]}.get(info["last_path"], info["last_path"])
     print("%-10s %5dx%-5d %-28s %-10s pivots %6d  %8.3f ms  %6.2f us/pivot" % (b["name"], t0.height, t0.width, kern, st, piv, best, 1e3 * best / max(piv, 1)), flush=True)
     t.close()

@@ -21,7 +21,7 @@ for M, Nn in shapes:
         st, res, piv, ms = t.solve(max_pivots=float("inf"))
         best = ms if best is None else min(best, ms)
     info = t.info()
-    kern = {"small": "small_kernel", "resident": info["resident"].split(" ")[0], "inplace": info["resident"].split(" ")[0],
+    kern = {"small": "small_kernel", "resident": info["resident"].split(" ")[0], "inplace": info["inplace"],
             "streaming": info["streaming"]}.get(info["last_path"], info["last_path"])
     us = 1e3 * best / max(piv, 1)
     rows.append({"tableau": "%dx%d" % (h, w), "kernel": kern, "status": st, "pivots": piv, "ms": round(best, 3),

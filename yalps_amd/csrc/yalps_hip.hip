@@ -546,18 +546,17 @@ int32_t yalps_tableau_height(const yalps_tableau *t) { return t ? t->height : 0;
 
 int32_t yalps_tableau_info(const yalps_tableau *t, char *buf, int32_t len) {
     if (!t || !buf || len < 1) return fail(YALPS_E_ARG, "yalps_tableau_info: bad argument");
-    char res[96] = "none";
+    char res[96] = "none", inp[64] = "none";
     if (t->rvar.fn)
         std::snprintf(res, sizeof res, "resident_kernel<%d,%d,%d> chunk=%d", t->rvar.T, t->rvar.J, t->rvar.R, RESIDENT_CHUNK);
-    else if (t->svar.fn)
-        std::snprintf(res, sizeof res, "stream_kernel<%d,%d> chunk=%d", t->svar.T, t->svar.J, RESIDENT_CHUNK);
+    if (t->svar.fn) std::snprintf(inp, sizeof inp, "stream_kernel<%d,%d>", t->svar.T, t->svar.J);
     char str[64];
     if (t->wfn)
         std::snprintf(str, sizeof str, "wide_kernel<%d,%d>", t->var.T, t->var.J);
     else
         std::snprintf(str, sizeof str, "pivot_kernel<%d,%d,%d>", t->var.T, t->var.J, t->var.R);
-    std::snprintf(buf, (size_t)len, "streaming=%s workgroups=%d resident=%s last_path=%s last_resident_launches=%lld", str,
-                  t->nb, res,
+    std::snprintf(buf, (size_t)len, "streaming=%s workgroups=%d resident=%s inplace=%s last_path=%s last_resident_launches=%lld", str,
+                  t->nb, res, inp,
                   t->last_path == 1 ? "resident" : t->last_path == 2 ? "streaming" : t->last_path == 3 ? "resident+streaming"
                   : t->last_path == 4 ? "small" : t->last_path == 8 ? "inplace" : t->last_path == 10 ? "inplace+streaming" : "none",
                   (long long)(t->last_path & 9 ? t->last_launches : 0));
