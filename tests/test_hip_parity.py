@@ -160,8 +160,8 @@ def test_solve_readme_example(nat):
 
 
 def test_resident_fallback_resumes_with_streaming_kernel(oracle, tmp_path):
-    """If the resident kernel ever reports a failed hand-off, the solve continues with the
-    streaming kernel from the last consistent state.  Forced here after two chunks of 40 pivots
+    """If the resident kernel ever reports a failed hand-off, the solve continues with the next
+    path (the in-place kernel) from the last consistent state.  Forced here after two chunks of 40 pivots
     (in a child process: the switches are read when the context is created)."""
     import subprocess
     import sys
@@ -175,7 +175,7 @@ def test_resident_fallback_resumes_with_streaming_kernel(oracle, tmp_path):
         "ctx = n.Context(0); t = n.DeviceTableau(ctx, rec['width'], rec['height']); t.upload(m, rec['height'], pos, var)\n"
         "st, res, piv, _ = t.solve(max_pivots=float('inf')); info = t.info(); gm, gp, gv = t.download()\n"
         "exp = G.expected(rec)\n"
-        "assert info['last_path'] == 'resident+streaming', info\n"
+        "assert info['last_path'] == 'resident+inplace', info\n"
         "assert (st, res, piv) == (exp['status'], exp['result'], exp['n_pivots']), (st, res, piv)\n"
         "assert G.sha256(gm) == exp['final_sha256'] and np.array_equal(gp, exp['pos']) and np.array_equal(gv, exp['var'])\n"
         "print('ok')\n" % ROOT)

@@ -558,7 +558,8 @@ int32_t yalps_tableau_info(const yalps_tableau *t, char *buf, int32_t len) {
     std::snprintf(buf, (size_t)len, "streaming=%s workgroups=%d resident=%s inplace=%s last_path=%s last_resident_launches=%lld", str,
                   t->nb, res, inp,
                   t->last_path == 1 ? "resident" : t->last_path == 2 ? "streaming" : t->last_path == 3 ? "resident+streaming"
-                  : t->last_path == 4 ? "small" : t->last_path == 8 ? "inplace" : t->last_path == 10 ? "inplace+streaming" : "none",
+                  : t->last_path == 4 ? "small" : t->last_path == 8 ? "inplace" : t->last_path == 10 ? "inplace+streaming"
+                  : t->last_path == 9 ? "resident+inplace" : t->last_path == 11 ? "resident+inplace+streaming" : "none",
                   (long long)(t->last_path & 9 ? t->last_launches : 0));
     return 0;
 }
@@ -839,10 +840,13 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
 
     // (a) persistent kernels, one launch = up to `chunk` pivots: the register-resident kernel when the tableau
     //     fits on chip, else the in-place streaming kernel
-    const bool persistent_ok = t->d.nshards == 1;
-    const bool use_resident = persistent_ok && c->resident && t->rvar.fn; // (checkCycles: one more exchange per pivot)
-    const bool use_stream = persistent_ok && !use_resident && c->inplace && (checkCycles ? t->svar_check.fn : t->svar.fn);
-    if (use_resident || use_stream) {
+    // (fall-back order: resident -> in place -> one launch per pivot; a path that fails is not tried again on this context)
+    int64_t hist_have = 0; // checkCycles: pivots recorded in the current phase at the next launch's start
+    for (int attempt = 0; attempt < 2 && !finished; attempt++) {
+        const bool persistent_ok = t->d.nshards == 1;
+        const bool use_resident = persistent_ok && c->resident && t->rvar.fn; // (checkCycles: one more exchange per pivot)
+        const bool use_stream = persistent_ok && !use_resident && c->inplace && (checkCycles ? t->svar_check.fn : t->svar.fn);
+        if (!use_resident && !use_stream) break;
         const bool in_place = use_stream;
         const RVariant &pv = in_place ? (checkCycles ? t->svar_check : t->svar) : t->rvar;
         bool &sattr = checkCycles ? t->sattr_check : t->sattr;
@@ -866,7 +870,7 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
         for (;;) {
             HIP_TRY(hipMemsetAsync(t->rc_sync, 0, t->rc_sync_bytes, s));
             if (checkCycles) { // room for every pivot this launch can record (no pause inside a persistent launch)
-                const int64_t have = parity == 0 && t->last_launches == 0 ? 0 : t->host_state[1].hist_len;
+                const int64_t have = hist_have;
                 if (have + chunk > t->hist_cap) {
                     rc = grow_history(t, have + chunk, have);
                     if (rc) return rc;
@@ -927,6 +931,7 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
                                            hipMemcpyDeviceToDevice, s));
                     t->cur = 0;
                 }
+                hist_have = last.hist_len;
                 last.mbuf = 0;
                 last.bootstrap = 1;
                 last.la = 0;
@@ -940,6 +945,7 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
                 break;
             }
             t->cur = t->host_state[1].mbuf; // (resident launches flip the buffer; in place it stays)
+            hist_have = t->host_state[1].hist_len;
             parity ^= 1;
         }
     }
