@@ -10,12 +10,14 @@
 //                        ping-ponged in HBM; also DECIDE/APPLY for checkCycles
 //   wide_kernel.cuh      streaming for tableaux too wide / tall for register batches (pivot row in LDS)
 //   shard_kernels.cuh    row-sharded solve across GPUs: per-rank select kernel (+ MODE_SHARD above)
+//   assemble_kernels.cuh initial tableau from its written cells; applyCuts (branch-and-cut nodes) in HBM
 //   stream_kernel.cuh    persistent in-place pivot loop for tableaux beyond the on-chip size
 //   wg_simplex.cuh       the whole simplex loop by one workgroup; small_kernel (tableau in LDS)
 //   batch_kernel.cuh     batched branch-and-cut nodes, one workgroup per node
-// Host side here: contexts, tableaux (HBM layout, upload/download), the solve drivers (resident
-// chunks with streaming fallback; hipGraph batches of 64 launches polled once per batch -- no host
-// round trip per pivot), shard steps, node batches, and the drop-in yalps_simplex_f64.
+// Host side here: contexts, tableaux (HBM layout, upload/download/assemble/apply_cuts), the solve driver
+// (one workgroup in LDS | persistent chunks: register-resident, then in place | hipGraph batches of 64
+// launches polled once per batch -- never a host round trip per pivot), shard steps, node batches, and
+// the host-array drop-ins yalps_simplex_f64 / yalps_simplex_sparse_f64.
 //
 // Bit-exactness contract (tests/ compare against the oracle bit for bit): separately rounded
 // multiply and subtract (-ffp-contract=off, checked in the ISA: v_mul_f64 + v_add_f64, no
