@@ -195,6 +195,8 @@ struct yalps_tableau {
     int64_t hist_cap = 0;
     void *cells = nullptr; // staging of yalps_tableau_assemble: row[] col[] val[] of cells_cap entries
     std::vector<char> cut_stage; // host side of yalps_tableau_apply_cuts' one packed upload
+    void *pin_out = nullptr;     // pinned staging of yalps_tableau_download_solution
+    size_t pin_out_bytes = 0;
     int64_t cells_cap = 0;
 };
 
@@ -253,7 +255,7 @@ int grow_history(yalps_tableau *t, int64_t need, int64_t keep) {
     return 0;
 }
 
-int init_state(yalps_tableau *t, double precision, double maxPivots, int32_t checkCycles) {
+int init_state(yalps_tableau *t, double precision, double maxPivots, int32_t checkCycles, bool wait = true) {
     hipStream_t s = t->ctx->stream;
     if (checkCycles && !t->hist_cap) {
         int rc = grow_history(t, 4096, 0);
@@ -266,7 +268,7 @@ int init_state(yalps_tableau *t, double precision, double maxPivots, int32_t che
         HIP_TRY(hipMemcpyAsync(d.rhs[0], d.rhs[1], sizeof(double) * (size_t)t->height, hipMemcpyDeviceToDevice, s));
         t->cur = 0;
     }
-    YConst hc;
+    YConst &hc = *reinterpret_cast<YConst *>(t->host_state + 4); // pinned, like the state slots
     std::memset(&hc, 0, sizeof hc);
     hc.height = t->height;
     hc.check_cycles = checkCycles ? 1 : 0;
@@ -284,7 +286,9 @@ int init_state(yalps_tableau *t, double precision, double maxPivots, int32_t che
     hs->mbuf = t->cur;
     hs->result = NAN;
     HIP_TRY(hipMemcpyAsync(t->d.st, hs, sizeof(YState), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s)); // slot 0 is reused by the polling loop
+    // (callers that go on to touch slot 0 from the host, or to copy on another stream, wait here; the solve
+    // driver does not: everything it enqueues is ordered behind these two copies on the same stream)
+    if (wait) HIP_TRY(hipStreamSynchronize(s));
     return 0;
 }
 
@@ -504,7 +508,7 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
         d.rc_verdict = base + 2 * nflag;
         d.rc_err = reinterpret_cast<int32_t *>(base + 2 * nflag + 2);
     }
-    HIP_TRY(hipHostMalloc(&t->host_state, sizeof(YState) * 4, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(&t->host_state, sizeof(YState) * 4 + sizeof(YConst), hipHostMallocDefault)); // 4 slots + YConst
     for (int k = 0; k < 4; k++) HIP_TRY(hipEventCreateWithFlags(&t->slot_ev[k], hipEventDisableTiming));
     HIP_TRY(hipStreamSynchronize(s));
     *out = t;
@@ -539,6 +543,7 @@ void yalps_tableau_destroy(yalps_tableau *t) {
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (t->host_state) (void)hipHostFree(t->host_state);
+    if (t->pin_out) (void)hipHostFree(t->pin_out);
     for (auto &e : t->slot_ev)
         if (e) (void)hipEventDestroy(e);
     delete t;
@@ -667,11 +672,24 @@ int32_t yalps_tableau_download_solution(yalps_tableau *t, double *col0, int32_t 
     if (!t || !col0 || !pos || !var) return fail(YALPS_E_ARG, "yalps_tableau_download_solution: NULL argument");
     HIP_TRY(hipSetDevice(t->ctx->device));
     hipStream_t s = t->ctx->stream;
-    const size_t nperm = sizeof(int32_t) * (size_t)t->perm_len;
-    HIP_TRY(hipMemcpyAsync(col0, t->d.rhs[t->cur], sizeof(double) * (size_t)t->height, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(pos, t->d.pos, nperm, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(var, t->d.var, nperm, hipMemcpyDeviceToHost, s));
+    // through pinned staging: three truly asynchronous copies and one wait (copies into pageable memory block one by one)
+    const size_t ncol = sizeof(double) * (size_t)t->height, nperm = sizeof(int32_t) * (size_t)t->perm_len;
+    if (ncol + 2 * nperm > t->pin_out_bytes) {
+        if (t->pin_out) HIP_TRY(hipHostFree(t->pin_out));
+        t->pin_out = nullptr;
+        t->pin_out_bytes = 0;
+        const size_t cap = sizeof(double) * (size_t)t->d.hcap + 2 * sizeof(int32_t) * ((size_t)t->perm_len + t->d.hcap) + 64;
+        HIP_TRY(hipHostMalloc(&t->pin_out, cap, hipHostMallocDefault));
+        t->pin_out_bytes = cap;
+    }
+    char *stage = static_cast<char *>(t->pin_out);
+    HIP_TRY(hipMemcpyAsync(stage, t->d.rhs[t->cur], ncol, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(stage + ncol, t->d.pos, nperm, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(stage + ncol + nperm, t->d.var, nperm, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    std::memcpy(col0, stage, ncol);
+    std::memcpy(pos, stage + ncol, nperm);
+    std::memcpy(var, stage + ncol + nperm, nperm);
     return 0;
 }
 
@@ -831,7 +849,7 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
         return run_small(c, sd, checkCycles, result_out, pivots_out, gpu_ms_out);
     }
     const int which = checkCycles ? 1 : 0;
-    int rc = init_state(t, precision, maxPivots, checkCycles);
+    int rc = init_state(t, precision, maxPivots, checkCycles, false);
     if (rc) return rc;
     if (gpu_ms_out) HIP_TRY(hipEventRecord(c->ev0, s));
     YState fin;
