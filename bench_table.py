@@ -8,7 +8,8 @@ TypeScript host's job), and what is timed is what this build replaces: the simpl
   lp_ms     one drop-in call yalps_simplex_f64 on host arrays (upload + solve + download), root LP
   lp_sparse_ms  the same LP through yalps_simplex_sparse_f64 (cells up, column 0 + permutations back)
   milp_ms   the whole branch and cut: sequential (one drop-in call per node), batched (node_batch=32), and with root
-            and nodes resident in HBM (device_nodes: yalps_tableau_apply_cuts)
+            and nodes resident in HBM (device_nodes: yalps_tableau_apply_cuts); native = the whole branch and cut in one
+            native call (yalps_milp_f64), one node at a time or in batches of 32
 next to the reference's published whole-solve() mean (unknown CPU, node 19) for orientation only.
 Then the reference's own harness (benchmarks/benchmark.ts, restated in yalps_amd/benchmark.py: 30
 samples per runner, compensated mean / stdDev / slowdown, validated results) over the same problems
@@ -67,11 +68,13 @@ def main():
                "cells": int(cells[0].size),
                "us_per_pivot": round(1e6 * min(lp) / max(piv, 1), 2), "reference_solve_ms_readme": ref_ms}
         if tm.integers:
-            for label, nb, dev in (("milp_sequential_ms", 0, False), ("milp_batched_ms", 32, False), ("milp_device_nodes_ms", 0, True)):
+            for label, nb, dev, nat in (("milp_sequential_ms", 0, False, False), ("milp_batched_ms", 32, False, False),
+                                        ("milp_device_nodes_ms", 0, True, False), ("milp_native_ms", 0, True, True),
+                                        ("milp_native_batched_ms", 32, True, True)):
                 ts = []
                 for _ in range(3):
                     t0 = time.perf_counter()
-                    sol = S.solve(mdl, opt, node_batch=nb, device_nodes=dev)
+                    sol = S.solve(mdl, opt, node_batch=nb, device_nodes=dev, native=nat)
                     ts.append(time.perf_counter() - t0)
                 row[label] = round(1e3 * min(ts), 2)  # includes the Python host (tableau build, heap, cuts)
             row["objective_ok"] = bool(K.result_is_optimal(sol["result"], expected, S.default_options | {"tolerance": opt.get("tolerance", 0)}))

@@ -37,6 +37,7 @@ extern "C" {
 #define YALPS_INFEASIBLE 1
 #define YALPS_UNBOUNDED 2
 #define YALPS_CYCLED 3
+#define YALPS_TIMEDOUT 4 /* only from yalps_milp_f64 (branch and cut: timeout / maxIterations, src/branchAndCut.ts:166-173) */
 
 #define YALPS_E_ARG (-1)    /* bad argument */
 #define YALPS_E_DEVICE (-2) /* no usable HIP device / HIP runtime error */
@@ -175,6 +176,24 @@ int32_t yalps_batch_solve(yalps_batch *b, int32_t count, const int32_t *cut_offs
 /* Node `node` of the last batch, `height` = root_height + its number of cuts; NULL pointers are skipped. */
 int32_t yalps_batch_download(yalps_batch *b, int32_t node, int32_t height, double *matrix, double *col0,
                              int32_t *positionOfVariable, int32_t *variableAtPosition);
+
+/* ---- the whole branch and cut in one native call (src/YALPS.ts:73-92 for a model with integers) ----------
+ * Input: the INITIAL tableau as tableauModel built it (row-major, identity permutations allowed but not required),
+ * the 1-based columns of the integer variables (TableauModel.integers, src/tableau.ts:57-71), `sign` (-1 minimise,
+ * +1 maximise, :51) and the options read on this path (src/types.ts:203-265; timeout in ms, may be +Infinity).
+ * Does simplex() on the root, then branchAndCut (src/branchAndCut.ts:89-176) with the reference's queue order
+ * (binary heap with heapq / heap.js sift rules, keyed by the parent's evaluation) and every node LP on the GPU:
+ * node_batch > 1 evaluates that many frontier nodes per launch (speculatively; results are committed in pop
+ * order), otherwise one node at a time with the root resident in HBM.
+ * Output: *status_out (YALPS_* incl. YALPS_TIMEDOUT), *result_out (best evaluation or NaN; root result when the
+ * root is not optimal), and what solution() reads of the best tableau: *height_out, column 0 (col0_out, room for
+ * height + 2*n_integers doubles) and both permutations (room for width + height + 2*n_integers entries).
+ * stats_out (optional, 3 x int64): nodes consumed, node LPs evaluated, batches.  Returns 0 or a negative error. */
+int32_t yalps_milp_f64(const double *matrix, int32_t width, int32_t height, const int32_t *positionOfVariable,
+                       const int32_t *variableAtPosition, const int32_t *integers, int32_t n_integers, double sign,
+                       double precision, double maxPivots, int32_t checkCycles, double tolerance, double timeout_ms,
+                       double maxIterations, int32_t node_batch, int32_t *status_out, double *result_out,
+                       double *col0_out, int32_t *pos_out, int32_t *var_out, int32_t *height_out, int64_t *stats_out);
 
 /* ---- synthetic input of the headline benchmark ---------------------------------------------
  * dense-LP(M,N,seed): fills a (M+1) x (N+1) row-major tableau with the

@@ -93,8 +93,8 @@ def test_batched_solve_equals_sequential(nat, name):
     if case["options"].get("checkCycles"):
         pytest.skip("checkCycles uses the one-node-at-a-time path")
     stats = {}
-    a = S.solve(case["model"], case["options"], node_batch=32, stats=stats)
-    b = S.solve(case["model"], case["options"], device_nodes=False)
+    a = S.solve(case["model"], case["options"], node_batch=32, stats=stats, native=False)
+    b = S.solve(case["model"], case["options"], device_nodes=False, native=False)
     assert a["status"] == b["status"] and G.same_number(a["result"], b["result"]) and a["variables"] == b["variables"]
     assert K.valid_solution_and_status(a, case["expected"], case["model"], case["options"])
     if "nodes_used" in stats:  # (roots above 4 MB take the device-resident one-node-at-a-time path instead)
@@ -142,6 +142,31 @@ def test_device_nodes_solve_equals_sequential(nat, name):
     opt.update(case["options"])
     stats = {}
     a = S._milp_on_device(M.tableau_model(case["model"], sparse=True), opt, stats)
-    b = S.solve(case["model"], case["options"], device_nodes=False)
+    b = S.solve(case["model"], case["options"], device_nodes=False, native=False)
     assert a["status"] == b["status"] and G.same_number(a["result"], b["result"]) and a["variables"] == b["variables"]
     assert K.valid_solution_and_status(a, case["expected"], case["model"], case["options"])
+
+
+# ---- the whole branch and cut in one native call (yalps_milp_f64) ----------------------------------
+@pytest.mark.parametrize("node_batch", [0, 32], ids=["one-at-a-time", "batches-of-32"])
+@pytest.mark.parametrize("name", INTEGER_CASES)
+def test_native_branch_and_cut_equals_reference_flow(nat, name, node_batch):
+    """yalps_milp_f64 (native heap with heapq / heap.js sift rules, nodes on the GPU) against the reference's flow
+    restated in Python (one drop-in simplex() call per node): same status, objective and variables; with batches
+    the same again (speculative evaluation commits in pop order)."""
+    case = K.load(name)
+    stats = {}
+    a = S.solve(case["model"], case["options"], node_batch=node_batch, stats=stats, native=True)
+    b = S.solve(case["model"], case["options"], device_nodes=False, native=False)
+    assert a["status"] == b["status"] and G.same_number(a["result"], b["result"]) and a["variables"] == b["variables"]
+    assert K.valid_solution_and_status(a, case["expected"], case["model"], case["options"])
+    assert stats["nodes_used"] <= stats["nodes_evaluated"] or stats["nodes_evaluated"] == 0
+
+
+def test_native_branch_and_cut_timeout_and_iteration_limit(nat):
+    case = K.load("Knapsack 1")
+    sol = S.solve(case["model"], {**case["options"], "timeout": 0})
+    assert sol["status"] == "timedout"  # tests/solver.ts:126-135
+    sol = S.solve(case["model"], {**case["options"], "maxIterations": 1})
+    ref = S.solve(case["model"], {**case["options"], "maxIterations": 1}, native=False, device_nodes=False)
+    assert sol["status"] == ref["status"] and G.same_number(sol["result"], ref["result"]) and sol["variables"] == ref["variables"]

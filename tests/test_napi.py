@@ -95,3 +95,36 @@ def test_addon_branch_and_cut_exports(oracle, name):
         assert (eres != eres and got["result"] == "NaN") or float(got["result"]) == eres
         assert np.array_equal(f64(got["col0"]).view(np.int64), m.reshape(cur.height, cur.width)[:, 0].view(np.int64))
         assert got["positionOfVariable"] == pos.tolist() and got["variableAtPosition"] == var.tolist()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,node_batch", [("Knapsack 1", 0), ("Large Farm MIP", 32), ("Integer Sports Complex Problem", 8)])
+def test_addon_solve_integer(name, node_batch):
+    """solveInteger under node = the whole solve() of a model with integers in one native call: the Solution built
+    from what it returns equals the Python restatement of the reference flow."""
+    from tests import _cases as K
+    from yalps_amd import model as M, solve as S
+    from yalps_amd.model import Tableau, TableauModel
+    case = K.load(name)
+    opt = dict(S.default_options)
+    opt.update(case["options"])
+    tabmod = M.tableau_model(case["model"])
+    t = tabmod.tableau
+    enc = lambda x: "Infinity" if x == float("inf") else x
+    job = {"matrix": t.matrix.tolist(), "width": t.width, "height": t.height, "integers": tabmod.integers, "sign": tabmod.sign,
+           "nodeBatch": node_batch, "options": {k: enc(opt[k]) for k in ("precision", "maxPivots", "checkCycles", "tolerance",
+                                                                           "timeout", "maxIterations")}}
+    out = subprocess.run(["node", os.path.join(ROOT, "yalps_amd", "napi", "run_milp.js")], input=json.dumps(job),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert "error" not in res, res
+    view = TableauModel(Tableau(None, t.width, res["height"], np.array(res["positionOfVariable"], np.int32),
+                                np.array(res["variableAtPosition"], np.int32),
+                                np.frombuffer(bytes.fromhex(res["col0"]), np.float64)), tabmod.sign, tabmod.variables, tabmod.integers)
+    result = float(res["result"]) if not isinstance(res["result"], str) else float("nan")
+    got = S.solution(view, res["status"], result, opt)
+    ref = S.solve(case["model"], case["options"], native=False, device_nodes=False)
+    assert got["status"] == ref["status"] and (got["result"] == ref["result"] or (got["result"] != got["result"] and ref["result"] != ref["result"]))
+    assert got["variables"] == ref["variables"]
+    assert K.valid_solution_and_status(got, case["expected"], case["model"], case["options"])

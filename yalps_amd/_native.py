@@ -11,7 +11,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("YALPS_HIP_LIB") or os.path.join(HERE, "libyalps_hip.so")  # (same switch as the N-API addon)
 
-STATUS = ("optimal", "infeasible", "unbounded", "cycled")
+STATUS = ("optimal", "infeasible", "unbounded", "cycled", "timedout")
 COPYBACK_FULL, COPYBACK_SOLUTION = 0, 1
 
 # every symbol include/yalps_hip.h declares
@@ -22,7 +22,7 @@ SYMBOLS = (
     "yalps_tableau_solve", "yalps_tableau_pivot", "yalps_tableau_bench_sweep", "yalps_dense_lp_f64",
     "yalps_round_to_precision", "yalps_ctx_create_on_stream", "yalps_tableau_set_shard", "yalps_shard_slot_doubles",
     "yalps_shard_begin", "yalps_shard_select", "yalps_shard_apply", "yalps_shard_poll", "yalps_tableau_info",
-    "yalps_tableau_assemble", "yalps_simplex_sparse_f64", "yalps_tableau_apply_cuts", "yalps_tableau_download_solution", "yalps_batch_create", "yalps_batch_destroy", "yalps_batch_set_root", "yalps_batch_solve", "yalps_batch_download",
+    "yalps_tableau_assemble", "yalps_simplex_sparse_f64", "yalps_tableau_apply_cuts", "yalps_tableau_download_solution", "yalps_milp_f64", "yalps_batch_create", "yalps_batch_destroy", "yalps_batch_set_root", "yalps_batch_solve", "yalps_batch_download",
 )
 
 
@@ -51,6 +51,10 @@ def lib():
         L.yalps_simplex_sparse_f64.restype = C.c_int32
         L.yalps_simplex_sparse_f64.argtypes = [C.c_int32, C.c_int32, C.c_int64, vp, vp, vp, C.c_double, C.c_double,
                                                C.c_int32, vp, vp, vp, f64p, C.POINTER(C.c_int64)]
+        L.yalps_milp_f64.restype = C.c_int32
+        L.yalps_milp_f64.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, C.c_int32, C.c_double, C.c_double, C.c_double,
+                                     C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32, C.POINTER(C.c_int32), f64p,
+                                     vp, vp, vp, C.POINTER(C.c_int32), vp]
         L.yalps_tableau_download_solution.restype = C.c_int32
         L.yalps_tableau_download_solution.argtypes = [vp, vp, vp, vp]
         L.yalps_tableau_apply_cuts.restype = C.c_int32
@@ -154,6 +158,25 @@ def simplex_sparse(width, height, row, col, val, precision=1e-8, max_pivots=8192
                                               int(bool(check_cycles)), col0.ctypes.data, pos.ctypes.data,
                                               var.ctypes.data, C.byref(res), C.byref(npiv)))
     return STATUS[st], res.value, npiv.value, col0, pos, var
+
+
+def milp(matrix, width, height, pos, var, integers, sign, precision=1e-8, max_pivots=8192.0, check_cycles=False,
+         tolerance=0.0, timeout=float("inf"), max_iterations=32768.0, node_batch=0):
+    """The whole branch and cut in one native call (yalps_milp_f64).  Returns (status, result, height, col0, pos, var,
+    stats) -- what solution() reads of the best tableau."""
+    ints = np.ascontiguousarray(integers, np.int32)
+    extra = 2 * ints.size
+    col0 = np.empty(height + extra, np.float64)
+    opos, ovar = np.empty(width + height + extra, np.int32), np.empty(width + height + extra, np.int32)
+    st, h, res, stats = C.c_int32(), C.c_int32(), C.c_double(), np.zeros(3, np.int64)
+    check(lib().yalps_milp_f64(_ptr(matrix, np.float64), width, height, _ptr(pos, np.int32), _ptr(var, np.int32),
+                               ints.ctypes.data, ints.size, float(sign), precision, float(max_pivots), int(bool(check_cycles)),
+                               float(tolerance), float(timeout), float(max_iterations), int(node_batch), C.byref(st),
+                               C.byref(res), col0.ctypes.data, opos.ctypes.data, ovar.ctypes.data, C.byref(h),
+                               stats.ctypes.data))
+    n = h.value
+    return (STATUS[st.value], res.value, n, col0[:n].copy(), opos[:width + n].copy(), ovar[:width + n].copy(),
+            {"nodes_used": int(stats[0]), "nodes_evaluated": int(stats[1]), "batches": int(stats[2])})
 
 
 class Context:

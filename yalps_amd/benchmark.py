@@ -123,7 +123,7 @@ def _with_infinite_pivots(options):
 hip_runner = Runner("YALPS-hip", lambda model, options: (model, _with_infinite_pivots(options)),
                     lambda inp: solve(inp[0], inp[1]), lambda s: s["result"])
 hip_dense_runner = Runner("YALPS-hip (host tableau, host nodes)", lambda model, options: (model, _with_infinite_pivots(options)),
-                          lambda inp: solve(inp[0], inp[1], sparse=False, device_nodes=False), lambda s: s["result"])
-hip_batched_runner = Runner("YALPS-hip (node batches of 32)", lambda model, options: (model, _with_infinite_pivots(options)),
-                            lambda inp: solve(inp[0], inp[1], node_batch=32), lambda s: s["result"])
+                          lambda inp: solve(inp[0], inp[1], sparse=False, device_nodes=False, native=False), lambda s: s["result"])
+hip_batched_runner = Runner("YALPS-hip (one node at a time)", lambda model, options: (model, _with_infinite_pivots(options)),
+                            lambda inp: solve(inp[0], inp[1], node_batch=0), lambda s: s["result"])
 runners = (hip_runner, hip_dense_runner, hip_batched_runner)

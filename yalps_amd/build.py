@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libyalps_hip.so")
 HIP_SRC = os.path.join(HERE, "csrc", "yalps_hip.hip")
-HIP_DEPS = [os.path.join(HERE, "csrc", f) for f in sorted(os.listdir(os.path.join(HERE, "csrc"))) if f.endswith(".cuh")]
+HIP_DEPS = [os.path.join(HERE, "csrc", f) for f in sorted(os.listdir(os.path.join(HERE, "csrc"))) if f.endswith((".cuh", ".inc"))]
 HEADER = os.path.join(ROOT, "include", "yalps_hip.h")
 NAPI_SRC = os.path.join(HERE, "napi", "yalps_napi.cc")
 NAPI_OUT = os.path.join(HERE, "napi", "yalps_napi.node")

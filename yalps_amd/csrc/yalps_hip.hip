@@ -14,6 +14,7 @@
 //   stream_kernel.cuh    persistent in-place pivot loop for tableaux beyond the on-chip size
 //   wg_simplex.cuh       the whole simplex loop by one workgroup; small_kernel (tableau in LDS)
 //   batch_kernel.cuh     batched branch-and-cut nodes, one workgroup per node
+//   milp_host.inc        (host C++) the whole branch and cut in one native call: yalps_milp_f64
 // Host side here: contexts, tableaux (HBM layout, upload/download/assemble/apply_cuts), the solve driver
 // (one workgroup in LDS | persistent chunks: register-resident, then in place | hipGraph batches of 64
 // launches polled once per batch -- never a host round trip per pivot), shard steps, node batches, and
@@ -26,13 +27,16 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -1451,5 +1455,7 @@ int32_t yalps_simplex_f64(double *matrix, int32_t width, int32_t height, int32_t
     return yalps_simplex_f64_ex(matrix, width, height, pos, var, precision, maxPivots, checkCycles,
                                 YALPS_COPYBACK_FULL, result_out, nullptr);
 }
+
+#include "milp_host.inc"
 
 } // extern "C"

@@ -15,6 +15,10 @@
 //   nodeSolve(handle, cuts, options, out) -> [status, number, height]  applyCuts (:22-61) + simplex (:127) on the
 //        device; cuts = [[sign, variable, value], ...]; out = {col0: Float64Array, positionOfVariable, variableAtPosition}
 //   rootFree(handle)
+// and, one step further, the whole of it in one native call (yalps_milp_f64: native heap, nodes in GPU batches):
+//   solveInteger(tableau, integers, sign, options, nodeBatch) -> [status, number, height]
+//        tableau = the INITIAL tableau; on return its column 0 (first `height` rows of a matrix that must have room
+//        for height + 2*integers.length rows) and both permutations are those of the best tableau
 //
 // libyalps_hip.so is loaded with dlopen from YALPS_HIP_LIB or next to this addon; a missing
 // library or GPU surfaces as a thrown JS Error (the reference itself never throws on this path,
@@ -45,6 +49,9 @@ int32_t (*g_tab_download_rhs)(void *, double *) = nullptr;
 int32_t (*g_tab_height)(const void *) = nullptr;
 int32_t (*g_tab_solve)(void *, double, double, int32_t, double *, int64_t *, float *) = nullptr;
 int32_t (*g_tab_apply_cuts)(void *, const void *, int32_t, const int32_t *, const int32_t *, const double *) = nullptr;
+int32_t (*g_milp)(const double *, int32_t, int32_t, const int32_t *, const int32_t *, const int32_t *, int32_t, double, double, double,
+                  int32_t, double, double, double, int32_t, int32_t *, double *, double *, int32_t *, int32_t *, int32_t *,
+                  int64_t *) = nullptr;
 std::string g_load_error;
 
 bool load_library() {
@@ -78,8 +85,9 @@ bool load_library() {
     g_tab_height = reinterpret_cast<decltype(g_tab_height)>(sym("yalps_tableau_height"));
     g_tab_solve = reinterpret_cast<decltype(g_tab_solve)>(sym("yalps_tableau_solve"));
     g_tab_apply_cuts = reinterpret_cast<decltype(g_tab_apply_cuts)>(sym("yalps_tableau_apply_cuts"));
+    g_milp = reinterpret_cast<decltype(g_milp)>(sym("yalps_milp_f64"));
     if (!g_simplex || !g_last_error || !g_ctx_create || !g_ctx_destroy || !g_tab_create || !g_tab_destroy || !g_tab_upload ||
-        !g_tab_download || !g_tab_download_rhs || !g_tab_height || !g_tab_solve || !g_tab_apply_cuts) {
+        !g_tab_download || !g_tab_download_rhs || !g_tab_height || !g_tab_solve || !g_tab_apply_cuts || !g_milp) {
         g_load_error = path + " does not export the yalps_* entry points of include/yalps_hip.h";
         g_simplex = nullptr;
         return false;
@@ -316,6 +324,64 @@ napi_value RootFree(napi_env env, napi_callback_info info) {
     return undef;
 }
 
+// solveInteger(tableau, integers, sign, options, nodeBatch) -> [status, number, height]
+napi_value SolveInteger(napi_env env, napi_callback_info info) {
+    size_t argc = 5;
+    napi_value argv[5];
+    if (napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr) != napi_ok || argc < 5)
+        return fail(env, "solveInteger(tableau, integers, sign, options, nodeBatch): five arguments expected");
+    if (!load_library()) return fail(env, g_load_error);
+    void *matrix = nullptr, *pos = nullptr, *var = nullptr, *ints = nullptr;
+    size_t nmat = 0, npos = 0, nvar = 0, nints = 0;
+    napi_value v;
+    int32_t width = 0, height = 0, node_batch = 0;
+    double sign = 1.0;
+    if (!get_typed(env, argv[0], "matrix", napi_float64_array, &matrix, &nmat) ||
+        !get_typed(env, argv[0], "positionOfVariable", napi_int32_array, &pos, &npos) ||
+        !get_typed(env, argv[0], "variableAtPosition", napi_int32_array, &var, &nvar) ||
+        !get_named(env, argv[0], "width", &v) || napi_get_value_int32(env, v, &width) != napi_ok ||
+        !get_named(env, argv[0], "height", &v) || napi_get_value_int32(env, v, &height) != napi_ok)
+        return fail(env, "solveInteger: tableau must be a Tableau (src/tableau.ts:9-15)");
+    bool is_typed = false;
+    napi_typedarray_type tt;
+    napi_value ab;
+    size_t off = 0;
+    if (napi_is_typedarray(env, argv[1], &is_typed) != napi_ok || !is_typed ||
+        napi_get_typedarray_info(env, argv[1], &tt, &nints, &ints, &ab, &off) != napi_ok || tt != napi_int32_array)
+        return fail(env, "solveInteger: integers must be an Int32Array of 1-based tableau columns");
+    if (napi_get_value_double(env, argv[2], &sign) != napi_ok || napi_get_value_int32(env, argv[4], &node_batch) != napi_ok)
+        return fail(env, "solveInteger: sign / nodeBatch must be numbers");
+    const size_t hmax = (size_t)height + 2 * nints;
+    if (width < 1 || height < 1 || nmat < (size_t)width * (size_t)height || npos < (size_t)width + hmax || nvar < (size_t)width + hmax)
+        return fail(env, "solveInteger: the permutations need room for width + height + 2*integers.length entries");
+    const Options o = read_options(env, argv[3]);
+    double tolerance = 0.0, timeout = INFINITY, max_iterations = 32768;
+    if (get_named(env, argv[3], "tolerance", &v)) napi_get_value_double(env, v, &tolerance);
+    if (get_named(env, argv[3], "timeout", &v)) napi_get_value_double(env, v, &timeout);
+    if (get_named(env, argv[3], "maxIterations", &v)) napi_get_value_double(env, v, &max_iterations);
+    std::string col0(hmax * sizeof(double), '\0');
+    double *c0 = reinterpret_cast<double *>(&col0[0]);
+    int32_t status = 0, best_height = 0;
+    double result = NAN;
+    const int32_t rc = g_milp(static_cast<double *>(matrix), width, height, static_cast<int32_t *>(pos), static_cast<int32_t *>(var),
+                              static_cast<int32_t *>(ints), (int32_t)nints, sign, o.precision, o.max_pivots, o.check_cycles ? 1 : 0,
+                              tolerance, timeout, max_iterations, node_batch, &status, &result, c0, static_cast<int32_t *>(pos),
+                              static_cast<int32_t *>(var), &best_height, nullptr);
+    if (rc < 0) return fail(env, std::string("yalps_hip: ") + g_last_error());
+    const size_t rows = nmat / (size_t)width; // column 0 of as many rows as the caller's matrix holds
+    for (size_t r = 0; r < (size_t)best_height && r < rows; r++) static_cast<double *>(matrix)[r * width] = c0[r];
+    static const char *const kStatus[] = {"optimal", "infeasible", "unbounded", "cycled", "timedout"};
+    napi_value out, s2, r2, h2;
+    napi_create_array_with_length(env, 3, &out);
+    napi_create_string_utf8(env, kStatus[status], NAPI_AUTO_LENGTH, &s2);
+    napi_create_double(env, result, &r2);
+    napi_create_int32(env, best_height, &h2);
+    napi_set_element(env, out, 0, s2);
+    napi_set_element(env, out, 1, r2);
+    napi_set_element(env, out, 2, h2);
+    return out;
+}
+
 napi_value Init(napi_env env, napi_value exports) {
     napi_value fn;
     napi_create_function(env, "simplex", NAPI_AUTO_LENGTH, Simplex, nullptr, &fn);
@@ -326,6 +392,8 @@ napi_value Init(napi_env env, napi_value exports) {
     napi_set_named_property(env, exports, "nodeSolve", fn);
     napi_create_function(env, "rootFree", NAPI_AUTO_LENGTH, RootFree, nullptr, &fn);
     napi_set_named_property(env, exports, "rootFree", fn);
+    napi_create_function(env, "solveInteger", NAPI_AUTO_LENGTH, SolveInteger, nullptr, &fn);
+    napi_set_named_property(env, exports, "solveInteger", fn);
     return exports;
 }
 
