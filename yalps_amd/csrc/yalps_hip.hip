@@ -1172,6 +1172,8 @@ struct yalps_batch {
     double *cut_val = nullptr;
     size_t shmem = 0;
     bool lds = false; // node tableaux fit in LDS: batch_kernel<.., true>
+    char *pin = nullptr; // pinned staging of batch_solve_fetch (inputs, then outputs)
+    size_t pin_bytes = 0;
     int32_t last_count = 0;
 };
 
@@ -1253,6 +1255,7 @@ void yalps_batch_destroy(yalps_batch *b) {
                     b->cut_off, b->cut_sign, b->cut_var, b->cut_val, b->d.status, b->d.height, b->d.result, b->d.pivots};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
+    if (b->pin) (void)hipHostFree(b->pin);
     delete b;
 }
 
@@ -1304,6 +1307,60 @@ int32_t yalps_batch_solve(yalps_batch *b, int32_t count, const int32_t *cut_offs
     if (pivots_out) HIP_TRY(hipMemcpyAsync(pivots_out, b->d.pivots, sizeof(int64_t) * (size_t)count, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (gpu_ms_out) HIP_TRY(hipEventElapsedTime(gpu_ms_out, c->ev0, c->ev1));
+    b->last_count = count;
+    return 0;
+}
+
+// One batch for the native branch-and-cut driver: cuts up, kernel, and per node status / result / column 0 / both
+// permutations back -- everything through one pinned staging buffer, ONE wait.  col0_all / pos_all / var_all are
+// count x hmax doubles and count x permmax int32 (node i at i * hmax / i * permmax).
+static int32_t batch_solve_fetch(yalps_batch *b, int32_t count, const int32_t *off, const int32_t *sign, const int32_t *var,
+                                 const double *val, double precision, double maxPivots, int32_t *status_out, double *result_out,
+                                 double *col0_all, int32_t *pos_all, int32_t *var_all) {
+    yalps_ctx *c = b->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const BatchDesc &d = b->d;
+    const size_t total = (size_t)off[count], n = (size_t)count;
+    const size_t in_off = 0, in_sign = in_off + 4 * (n + 1), in_var = in_sign + 4 * total, in_val = (in_var + 4 * total + 7) & ~(size_t)7;
+    const size_t out_st = in_val + 8 * total, out_res = (out_st + 4 * n + 7) & ~(size_t)7, out_col0 = out_res + 8 * n;
+    const size_t out_pos = out_col0 + 8 * n * d.hmax, out_var = out_pos + 4 * n * d.permmax, bytes = out_var + 4 * n * d.permmax;
+    if (bytes > b->pin_bytes) {
+        if (b->pin) HIP_TRY(hipHostFree(b->pin));
+        b->pin = nullptr;
+        b->pin_bytes = 0;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->pin), 2 * bytes, hipHostMallocDefault));
+        b->pin_bytes = 2 * bytes;
+    }
+    char *p = b->pin;
+    std::memcpy(p + in_off, off, 4 * (n + 1));
+    std::memcpy(p + in_sign, sign, 4 * total);
+    std::memcpy(p + in_var, var, 4 * total);
+    std::memcpy(p + in_val, val, 8 * total);
+    HIP_TRY(hipMemcpyAsync(b->cut_off, p + in_off, 4 * (n + 1), hipMemcpyHostToDevice, s));
+    if (total > 0) {
+        HIP_TRY(hipMemcpyAsync(b->cut_sign, p + in_sign, 4 * total, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(b->cut_var, p + in_var, 4 * total, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(b->cut_val, p + in_val, 8 * total, hipMemcpyHostToDevice, s));
+    }
+    b->d.precision = precision;
+    b->d.max_pivots = maxPivots;
+    if (b->lds)
+        batch_kernel<256, true><<<dim3(count), dim3(256), b->shmem, s>>>(b->d);
+    else
+        batch_kernel<1024, false><<<dim3(count), dim3(1024), b->shmem, s>>>(b->d);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(p + out_st, d.status, 4 * n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(p + out_res, d.result, 8 * n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(p + out_col0, d.ws_rhs, 8 * n * d.hmax, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(p + out_pos, d.ws_pos, 4 * n * d.permmax, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(p + out_var, d.ws_var, 4 * n * d.permmax, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    std::memcpy(status_out, p + out_st, 4 * n);
+    std::memcpy(result_out, p + out_res, 8 * n);
+    std::memcpy(col0_all, p + out_col0, 8 * n * d.hmax);
+    std::memcpy(pos_all, p + out_pos, 4 * n * d.permmax);
+    std::memcpy(var_all, p + out_var, 4 * n * d.permmax);
     b->last_count = count;
     return 0;
 }
