@@ -86,7 +86,8 @@ int32_t yalps_ctx_create(int32_t device, yalps_ctx **out);
 int32_t yalps_ctx_create_on_stream(int32_t device, void *hip_stream, yalps_ctx **out);
 void yalps_ctx_destroy(yalps_ctx *ctx);
 
-/* A tableau of `width` columns and room for up to `height_capacity` rows. */
+/* A tableau of `width` columns and room for up to `height_capacity` rows (any width: rows wider than 16385 columns
+ * are solved by an untuned any-shape kernel pair). */
 int32_t yalps_tableau_create(yalps_ctx *ctx, int32_t width, int32_t height_capacity,
                              yalps_tableau **out);
 void yalps_tableau_destroy(yalps_tableau *t);

@@ -657,3 +657,62 @@ def test_degenerate_integer_lps_on_every_path(nat, oracle, monkeypatch, path, en
     finally:
         c.close()
     assert {"optimal", "unbounded"} <= seen, seen
+
+
+# ---- rows wider than 16385 columns: the any-shape DECIDE + APPLY pair (generic_kernels.cuh) ---------------
+@pytest.mark.parametrize("M,N,pivots,check", [(200, 20000, 90, False), (60, 17000, 5000, False), (400, 33000, 60, True)])
+def test_generic_path_for_very_wide_tableaux(nat, ctx, M, N, pivots, check):
+    """The reference has no width limit; the tuned kernels stop at 16385 columns.  Beyond that every pivot is one
+    single-workgroup DECIDE launch + one in-place APPLY launch, bit-exact against the numpy restatement (phase 1,
+    exact zeros, a whole solve to optimality, and checkCycles staying silent)."""
+    from tests import _np_simplex as NP
+    w, h = N + 1, M + 1
+    m = nat.dense_lp(M, N, 31)
+    A = m.reshape(h, w)
+    if pivots < 5000:  # (the whole-solve case stays a plain LP: it reaches its optimum in 230 pivots)
+        A[h // 3] *= -1.0
+        A[3::5, 7::11] = 0.0
+    pos, var = np.arange(w + h, dtype=np.int32), np.arange(w + h, dtype=np.int32)
+    ref, rpos, rvar = m.copy(), pos.copy(), var.copy()
+    est, eres, epiv = NP.simplex(ref, w, h, rpos, rvar, max_pivots=pivots)
+    assert est == ("optimal" if pivots == 5000 else "cycled")
+    t = nat.DeviceTableau(ctx, w, h)
+    try:
+        t.upload(m, h, pos, var)
+        status, result, npiv, _ = t.solve(max_pivots=pivots, check_cycles=check)
+        assert t.info()["last_path"] == "generic", t.info()
+        got, gpos, gvar = t.download()
+    finally:
+        t.close()
+    assert (status, npiv) == (est, epiv) and G.same_number(result, eres)
+    assert np.array_equal(gpos, rpos) and np.array_equal(gvar, rvar)
+    assert np.array_equal(got.view(np.int64), ref.view(np.int64))
+    if pivots == 5000:  # and through the host-array drop-in
+        hm, hp, hv = m.copy(), pos.copy(), var.copy()
+        status, result, npiv = nat.simplex_host(hm, w, h, hp, hv, max_pivots=5000)
+        assert (status, npiv) == (est, epiv) and np.array_equal(hm.view(np.int64), ref.view(np.int64)) and np.array_equal(hp, rpos)
+
+
+def test_golden_cases_through_the_generic_pair(nat, oracle, monkeypatch):
+    """Every small golden record of the reference (all statuses, "cycled" by hasCycle, odd precisions / maxPivots)
+    through generic_decide_kernel + generic_apply_kernel (forced with YALPS_HIP_GENERIC=1, read at tableau creation)."""
+    monkeypatch.setenv("YALPS_HIP_SMALL", "0")
+    monkeypatch.setenv("YALPS_HIP_GENERIC", "1")
+    c = nat.Context(0)
+    try:
+        for rec in G.records("cases") + G.records("mixed") + [r for r in G.records("dense") if r["M"] <= 128]:
+            m = G.initial_matrix(rec, oracle, dense_gen=nat.dense_lp)
+            pos, var = G.identity_perms(rec)
+            exp = G.expected(rec)
+            t = nat.DeviceTableau(c, rec["width"], rec["height"])
+            try:
+                t.upload(m, rec["height"], pos, var)
+                st, res, piv, _ = t.solve(**G.options(rec))
+                assert t.info()["last_path"] == "generic"
+                gm, gp, gv = t.download()
+            finally:
+                t.close()
+            assert (st, piv) == (exp["status"], exp["n_pivots"]) and G.same_number(res, exp["result"]), G.label(rec)
+            assert G.sha256(gm) == exp["final_sha256"] and np.array_equal(gp, exp["pos"]) and np.array_equal(gv, exp["var"])
+    finally:
+        c.close()

@@ -75,6 +75,8 @@ struct Desc {
     int32_t *rc_err;                // set when a workgroup gives up waiting (never expected)
     unsigned long long *rc_verdict; // [2] checkCycles: workgroup 0's verdict on the pivot of an epoch, (epoch << 32) | cycled
     int32_t perm_len;
+    // any-shape fallback (generic_kernels.cuh): the normalised pivot row [pitch] and {quotient, its RHS, RHS non-zero}
+    double *gen_prow, *gen_scal;
 };
 
 // ------------------------------------------------------------------------------------------

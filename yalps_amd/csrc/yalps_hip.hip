@@ -12,6 +12,7 @@
 //   shard_kernels.cuh    row-sharded solve across GPUs: per-rank select kernel (+ MODE_SHARD above)
 //   assemble_kernels.cuh initial tableau from its written cells; applyCuts (branch-and-cut nodes) in HBM
 //   stream_kernel.cuh    persistent in-place pivot loop for tableaux beyond the on-chip size
+//   generic_kernels.cuh  any-shape fallback (rows wider than 16385 columns): DECIDE + APPLY launch per pivot
 //   wg_simplex.cuh       the whole simplex loop by one workgroup; small_kernel (tableau in LDS)
 //   batch_kernel.cuh     batched branch-and-cut nodes, one workgroup per node
 //   milp_host.inc        (host C++) the whole branch and cut in one native call: yalps_milp_f64
@@ -53,6 +54,7 @@ namespace {
 #include "assemble_kernels.cuh"
 #include "resident_kernel.cuh"
 #include "stream_kernel.cuh"
+#include "generic_kernels.cuh"
 #include "wg_simplex.cuh"
 #include "batch_kernel.cuh"
 
@@ -171,6 +173,7 @@ struct yalps_tableau {
     Desc d{};
     int32_t height = 0;
     int cur = 0; // tableau buffer holding the current tableau
+    bool generic = false; // no tuned kernel spans this shape: generic_decide_kernel / generic_apply_kernel (in place)
     int shard_parity = 0;
     RVariant rvar{0, 0, 0, nullptr}; // resident kernel variant, fn == nullptr: tableau does not fit
     void *rc_sync = nullptr; // flags[2], verdict[2], error word of the persistent kernels (one allocation)
@@ -412,11 +415,16 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
     int T = units <= 512 ? 256 : 1024;
     int J = 1;
     while (T * J < units) J *= 2;
-    if (J > 8) return fail(YALPS_E_ARG, "width > 16385 columns is not supported by this build");
     HIP_TRY(hipSetDevice(ctx->device));
     yalps_tableau *t = new yalps_tableau();
     t->ctx = ctx;
     *out = t; // reachable from now on: the wrapper frees a half-built object on failure
+    if (J > 8) { // rows wider than 16385 columns: the any-shape pair of generic_kernels.cuh (run-time loops only)
+        t->generic = true;
+        T = 1024;
+        J = 8;
+    }
+    if (env_int("YALPS_HIP_GENERIC", 0)) t->generic = true; // (test hook: any shape through the any-shape pair)
     const int forceR = env_int("YALPS_HIP_ROWS", 0);
     // spread the rows over all workgroups; rows in flight per lane R >= rows per workgroup if any
     // variant allows it (one batch per launch), else the largest R (several batches)
@@ -435,8 +443,8 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
         for (const WVariant &v : kWide)
             if (v.T == T && v.J == J) t->wfn = v.fn;
         t->wshmem = sizeof(double) * ((size_t)((n + 15) / 16 * 16 < 16 ? 16 : (n + 15) / 16 * 16) + 2 * (size_t)rows_per_block);
-        if (t->wshmem > 150 * 1024) return fail(YALPS_E_ARG, "tableau too wide for this build");
-        if (t->wshmem > 48 * 1024)
+        if (t->wshmem > 150 * 1024) t->generic = true; // (pivot row + per-row scalars exceed LDS)
+        if (!t->generic && t->wshmem > 48 * 1024)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(t->wfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)t->wshmem));
     }
@@ -455,10 +463,14 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
     if (d.pitch < 16) d.pitch = 16;
     const size_t mat_bytes = sizeof(double) * (size_t)d.pitch * hcap;
     hipStream_t s = ctx->stream;
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < (t->generic ? 1 : 2); k++) { // (the any-shape pair works in place: one buffer)
         HIP_TRY(hipMalloc(&d.mat[k], mat_bytes));
         HIP_TRY(hipMemsetAsync(d.mat[k], 0, mat_bytes, s));
         HIP_TRY(hipMalloc(&d.rhs[k], sizeof(double) * (size_t)hcap));
+    }
+    if (t->generic) {
+        HIP_TRY(hipMalloc(&d.gen_prow, sizeof(double) * (size_t)d.pitch));
+        HIP_TRY(hipMalloc(&d.gen_scal, sizeof(double) * 4));
     }
     HIP_TRY(hipMalloc(&d.pos, sizeof(int32_t) * (size_t)(width + hcap)));
     HIP_TRY(hipMalloc(&d.var, sizeof(int32_t) * (size_t)(width + hcap)));
@@ -472,7 +484,7 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
     // resident (on-chip) solver: needs every workgroup co-resident (one per CU) and the rows of a
     // workgroup in registers
     d.perm_len = t->perm_len;
-    if (t->nb <= ctx->num_cus) {
+    if (t->nb <= ctx->num_cus && !t->generic) {
         // (16 waves per CU were tried for 2049^2: <1024,1,9> spills at the 128-VGPR cap and its barriers
         // cost more: 92 K pivots/s against 144 K for <512,2,9>)
         int best = INT_MAX, fT = 0, fJ = 0, fR = 0;
@@ -489,7 +501,7 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
     }
     // persistent in-place kernel for what does not fit on chip: lanes x units span the row, the normalised
     // pivot row + my rows' scalars fit in LDS
-    if (t->nb <= ctx->num_cus) { // (also where a resident variant exists: the fallback order is resident, in place, launches)
+    if (t->nb <= ctx->num_cus && !t->generic) { // (also where a resident variant exists: the fallback order is resident, in place, launches)
         for (const RVariant &v : kStream)
             if (v.T == T && v.J == J) t->svar = v;
         for (const RVariant &v : kStreamCheck)
@@ -542,7 +554,7 @@ void yalps_tableau_destroy(yalps_tableau *t) {
     }
     Desc &d = t->d;
     void *bufs[] = {d.mat[0], d.mat[1], d.rhs[0], d.rhs[1], d.pos, d.var, d.st, d.cst, d.rc_rows[0], d.rc_rows[1], t->perm_backup,
-                    d.rc_key[0], d.rc_key[1], t->rc_sync, d.part_ratio[0], d.part_ratio[1], d.part_rhs[0], d.part_rhs[1],
+                    d.rc_key[0], d.rc_key[1], t->rc_sync, d.gen_prow, d.gen_scal, d.part_ratio[0], d.part_ratio[1], d.part_rhs[0], d.part_rhs[1],
                     t->hist[0], t->hist[1], t->cells};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
@@ -570,7 +582,8 @@ int32_t yalps_tableau_info(const yalps_tableau *t, char *buf, int32_t len) {
                   t->nb, res, inp,
                   t->last_path == 1 ? "resident" : t->last_path == 2 ? "streaming" : t->last_path == 3 ? "resident+streaming"
                   : t->last_path == 4 ? "small" : t->last_path == 8 ? "inplace" : t->last_path == 10 ? "inplace+streaming"
-                  : t->last_path == 9 ? "resident+inplace" : t->last_path == 11 ? "resident+inplace+streaming" : "none",
+                  : t->last_path == 9 ? "resident+inplace" : t->last_path == 11 ? "resident+inplace+streaming"
+                  : t->last_path == 16 ? "generic" : "none",
                   (long long)(t->last_path & 9 ? t->last_launches : 0));
     return 0;
 }
@@ -775,6 +788,60 @@ int32_t yalps_tableau_apply_cuts(yalps_tableau *dst, const yalps_tableau *root, 
     return 0;
 }
 
+// Any-shape fallback (generic_kernels.cuh): batches of DECIDE + APPLY launch pairs, state read back once per batch.
+static int32_t solve_generic(yalps_tableau *t, double precision, double maxPivots, int32_t checkCycles, double *result_out,
+                             int64_t *pivots_out, float *gpu_ms_out) {
+    yalps_ctx *c = t->ctx;
+    hipStream_t s = c->stream;
+    if (t->d.nshards > 1) return fail(YALPS_E_ARG, "row shards of this width are not supported");
+    int rc = init_state(t, precision, maxPivots, checkCycles);
+    if (rc) return rc;
+    const int nb = t->nb, rpw = (t->d.hcap + nb - 1) / nb;
+    const size_t shmem = sizeof(double) * (size_t)rpw;
+    if (shmem > 150 * 1024) return fail(YALPS_E_ARG, "tableau too tall for this build");
+    if (shmem > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(generic_apply_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)shmem));
+    constexpr int PAIRS = 32;
+    if (gpu_ms_out) HIP_TRY(hipEventRecord(c->ev0, s));
+    t->last_path = 16;
+    t->last_launches = 0;
+    int64_t hist_have = 0;
+    YState fin;
+    for (;;) {
+        if (checkCycles && hist_have + PAIRS > t->hist_cap) { // room for every pivot a batch can record
+            rc = grow_history(t, hist_have + PAIRS, hist_have);
+            if (rc) return rc;
+            YConst hc;
+            HIP_TRY(hipMemcpy(&hc, t->d.cst, sizeof(YConst), hipMemcpyDeviceToHost));
+            hc.hist_cap = t->hist_cap;
+            hc.hist_leaving = t->hist[0];
+            hc.hist_entering = t->hist[1];
+            HIP_TRY(hipMemcpy(t->d.cst, &hc, sizeof(YConst), hipMemcpyHostToDevice));
+        }
+        for (int i = 0; i < PAIRS; i++) {
+            generic_decide_kernel<<<dim3(1), dim3(1024), 0, s>>>(t->d);
+            generic_apply_kernel<<<dim3(nb), dim3(1024), shmem, s>>>(t->d);
+        }
+        t->last_launches += 2 * PAIRS;
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&t->host_state[1], t->d.st, sizeof(YState), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        fin = t->host_state[1];
+        if (fin.status != RUNNING) break;
+        hist_have = fin.hist_len;
+    }
+    if (gpu_ms_out) {
+        HIP_TRY(hipEventRecord(c->ev1, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipEventElapsedTime(gpu_ms_out, c->ev0, c->ev1));
+    }
+    t->cur = 0;
+    if (result_out) *result_out = fin.result;
+    if (pivots_out) *pivots_out = fin.pivots;
+    return fin.status;
+}
+
 // One launch of small_kernel on the context's stream and the wait for it; the kernel leaves status /
 // result / pivot count in pinned host memory.
 static int32_t run_small(yalps_ctx *c, SmallDesc sd, int32_t checkCycles, double *result_out, int64_t *pivots_out,
@@ -852,6 +919,7 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
         t->last_launches = 1;
         return run_small(c, sd, checkCycles, result_out, pivots_out, gpu_ms_out);
     }
+    if (t->generic) return solve_generic(t, precision, maxPivots, checkCycles, result_out, pivots_out, gpu_ms_out);
     const int which = checkCycles ? 1 : 0;
     int rc = init_state(t, precision, maxPivots, checkCycles, false);
     if (rc) return rc;
@@ -1047,6 +1115,7 @@ static int32_t set_decision(yalps_tableau *t, int32_t row, int32_t col) {
 int32_t yalps_tableau_pivot(yalps_tableau *t, int32_t row, int32_t col) {
     if (!t || t->height < 1) return fail(YALPS_E_ARG, "yalps_tableau_pivot: no tableau uploaded");
     if (row < 0 || row >= t->height || col < 1 || col >= t->d.w) return fail(YALPS_E_ARG, "pivot out of range");
+    if (t->generic) return fail(YALPS_E_ARG, "yalps_tableau_pivot: not available for tableaux wider than 16385 columns");
     HIP_TRY(hipSetDevice(t->ctx->device));
     int rc = set_decision(t, row, col);
     if (rc) return rc;
@@ -1061,6 +1130,7 @@ int32_t yalps_tableau_pivot(yalps_tableau *t, int32_t row, int32_t col) {
 int32_t yalps_tableau_bench_sweep(yalps_tableau *t, int32_t row, int32_t col, int32_t launches, float *avg_us_out) {
     if (!t || t->height < 1 || launches < 1) return fail(YALPS_E_ARG, "yalps_tableau_bench_sweep: bad argument");
     if (row < 0 || row >= t->height || col < 1 || col >= t->d.w) return fail(YALPS_E_ARG, "pivot out of range");
+    if (t->generic) return fail(YALPS_E_ARG, "yalps_tableau_bench_sweep: not available for tableaux wider than 16385 columns");
     yalps_ctx *c = t->ctx;
     HIP_TRY(hipSetDevice(c->device));
     int rc = set_decision(t, row, col);
@@ -1090,6 +1160,7 @@ int32_t yalps_tableau_set_shard(yalps_tableau *t, int32_t rank, int32_t nranks, 
         return fail(YALPS_E_ARG, "yalps_tableau_set_shard: bad argument");
     if (t->height != 1 + bounds[rank + 1] - bounds[rank] || bounds[0] != 1 || bounds[nranks] != global_height)
         return fail(YALPS_E_ARG, "yalps_tableau_set_shard: uploaded rows do not match bounds (objective row + own rows)");
+    if (t->generic) return fail(YALPS_E_ARG, "yalps_tableau_set_shard: row shards wider than 16385 columns are not supported");
     HIP_TRY(hipSetDevice(t->ctx->device));
     hipStream_t s = t->ctx->stream;
     Desc &d = t->d;
