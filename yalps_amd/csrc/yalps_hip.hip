@@ -1584,6 +1584,6 @@ int32_t yalps_simplex_f64(double *matrix, int32_t width, int32_t height, int32_t
                                 YALPS_COPYBACK_FULL, result_out, nullptr);
 }
 
-#include "milp_host.inc"
-
 } // extern "C"
+
+#include "milp_host.inc"
