@@ -1487,12 +1487,10 @@ int default_tableau(int32_t width, int32_t height, yalps_tableau **out) {
 }
 } // namespace
 
-int32_t yalps_simplex_f64_ex(double *matrix, int32_t width, int32_t height, int32_t *pos, int32_t *var,
-                             double precision, double maxPivots, int32_t checkCycles, int32_t copyback,
-                             double *result_out, int64_t *pivots_out) {
-    if (!matrix || !pos || !var || width < 1 || height < 1)
-        return fail(YALPS_E_ARG, "yalps_simplex_f64: bad argument");
-    std::lock_guard<std::mutex> lock(g_default_mu);
+// (g_default_mu held by the caller: the public entry point below, or yalps_milp_f64 for its host-side nodes)
+static int32_t simplex_f64_locked(double *matrix, int32_t width, int32_t height, int32_t *pos, int32_t *var,
+                                  double precision, double maxPivots, int32_t checkCycles, int32_t copyback,
+                                  double *result_out, int64_t *pivots_out) {
     yalps_tableau *t = nullptr;
     int rc = default_ctx();
     if (rc) return rc;
@@ -1555,6 +1553,15 @@ int32_t yalps_simplex_f64_ex(double *matrix, int32_t width, int32_t height, int3
     }
     if (rc) return rc;
     return status;
+}
+
+int32_t yalps_simplex_f64_ex(double *matrix, int32_t width, int32_t height, int32_t *pos, int32_t *var,
+                             double precision, double maxPivots, int32_t checkCycles, int32_t copyback,
+                             double *result_out, int64_t *pivots_out) {
+    if (!matrix || !pos || !var || width < 1 || height < 1)
+        return fail(YALPS_E_ARG, "yalps_simplex_f64: bad argument");
+    std::lock_guard<std::mutex> lock(g_default_mu);
+    return simplex_f64_locked(matrix, width, height, pos, var, precision, maxPivots, checkCycles, copyback, result_out, pivots_out);
 }
 
 int32_t yalps_simplex_sparse_f64(int32_t width, int32_t height, int64_t nnz, const int32_t *row, const int32_t *col,
