@@ -170,3 +170,33 @@ def test_native_branch_and_cut_timeout_and_iteration_limit(nat):
     sol = S.solve(case["model"], {**case["options"], "maxIterations": 1})
     ref = S.solve(case["model"], {**case["options"], "maxIterations": 1}, native=False, device_nodes=False)
     assert sol["status"] == ref["status"] and G.same_number(sol["result"], ref["result"]) and sol["variables"] == ref["variables"]
+
+
+def test_native_branch_and_cut_on_random_milps(nat):
+    """Seeded random small MILPs (knapsack-like rows, integer and binary variables, both directions, a tolerance now
+    and then): the native driver, one node at a time and in batches, against the Python restatement of the reference
+    flow -- same status, objective and variables (so the same queue order and the same node LPs)."""
+    rng = np.random.default_rng(77)
+    seen = set()
+    for case in range(60):
+        nv, nc = int(rng.integers(2, 9)), int(rng.integers(1, 6))
+        variables = {}
+        for v in range(nv):
+            coefs = {"c%d" % c: float(rng.integers(0, 9)) for c in range(nc) if rng.random() < 0.8}
+            coefs["obj"] = float(rng.integers(1, 20))
+            variables["x%d" % v] = coefs
+        constraints = {"c%d" % c: ({"max": float(rng.integers(5, 40))} if rng.random() < 0.8 else
+                                   {"min": float(rng.integers(1, 5)), "max": float(rng.integers(20, 60))}) for c in range(nc)}
+        keys = list(variables)
+        ints = [k for k in keys if rng.random() < 0.7]
+        bins = [k for k in keys if k not in ints and rng.random() < 0.5]
+        model = {"direction": "maximize" if rng.random() < 0.7 else "minimize", "objective": "obj", "constraints": constraints,
+                 "variables": variables, "integers": ints, "binaries": bins}
+        options = {"tolerance": float(rng.choice([0.0, 0.0, 0.05])), "maxIterations": int(rng.choice([32768, 32768, 6]))}
+        ref = S.solve(model, options, native=False, device_nodes=False)
+        seen.add(ref["status"])
+        for nb in (0, 16):
+            got = S.solve(model, options, node_batch=nb, native=True)
+            assert got["status"] == ref["status"] and G.same_number(got["result"], ref["result"]), (case, nb, got, ref)
+            assert got["variables"] == ref["variables"], (case, nb)
+    assert "optimal" in seen and len(seen) >= 2, seen
