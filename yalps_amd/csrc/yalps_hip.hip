@@ -1245,8 +1245,44 @@ struct yalps_batch {
     bool lds = false; // node tableaux fit in LDS: batch_kernel<.., true>
     char *pin = nullptr; // pinned staging of batch_solve_fetch (inputs, then outputs)
     size_t pin_bytes = 0;
+    void *in_block = nullptr, *out_block = nullptr; // device: cut lists | per-node results (see batch_layout)
+    size_t in_bytes = 0, out_bytes = 0;
+    size_t lay_in[4] = {0, 0, 0, 0}, lay_out[5] = {0, 0, 0, 0, 0}, lay_in_total = 0, lay_out_total = 0;
     int32_t last_count = 0;
 };
+
+// Lays the cut lists of `count` nodes with `total` cuts and the per-node outputs out inside the two device blocks and
+// points the descriptor (and the host-side staging offsets) at them.
+static void batch_layout(yalps_batch *b, size_t count, size_t total) {
+    BatchDesc &d = b->d;
+    auto up8 = [](size_t x) { return (x + 7) & ~(size_t)7; };
+    b->lay_in[0] = 0;                                        // value[total]
+    b->lay_in[1] = up8(b->lay_in[0] + 8 * total);            // offsets[count + 1]
+    b->lay_in[2] = up8(b->lay_in[1] + 4 * (count + 1));      // sign[total]
+    b->lay_in[3] = up8(b->lay_in[2] + 4 * total);            // variable[total]
+    b->lay_in_total = up8(b->lay_in[3] + 4 * total);
+    char *in = static_cast<char *>(b->in_block);
+    b->cut_val = reinterpret_cast<double *>(in + b->lay_in[0]);
+    b->cut_off = reinterpret_cast<int32_t *>(in + b->lay_in[1]);
+    b->cut_sign = reinterpret_cast<int32_t *>(in + b->lay_in[2]);
+    b->cut_var = reinterpret_cast<int32_t *>(in + b->lay_in[3]);
+    d.cut_val = b->cut_val;
+    d.cut_off = b->cut_off;
+    d.cut_sign = b->cut_sign;
+    d.cut_var = b->cut_var;
+    b->lay_out[0] = 0;                                                   // result[count]
+    b->lay_out[1] = up8(b->lay_out[0] + 8 * count);                      // column 0: count x hmax
+    b->lay_out[2] = up8(b->lay_out[1] + 8 * count * d.hmax);             // status[count]
+    b->lay_out[3] = up8(b->lay_out[2] + 4 * count);                      // positionOfVariable: count x permmax
+    b->lay_out[4] = up8(b->lay_out[3] + 4 * count * d.permmax);          // variableAtPosition: count x permmax
+    b->lay_out_total = up8(b->lay_out[4] + 4 * count * d.permmax);
+    char *out = static_cast<char *>(b->out_block);
+    d.result = reinterpret_cast<double *>(out + b->lay_out[0]);
+    d.ws_rhs = reinterpret_cast<double *>(out + b->lay_out[1]);
+    d.status = reinterpret_cast<int32_t *>(out + b->lay_out[2]);
+    d.ws_pos = reinterpret_cast<int32_t *>(out + b->lay_out[3]);
+    d.ws_var = reinterpret_cast<int32_t *>(out + b->lay_out[4]);
+}
 
 static int32_t batch_create_impl(yalps_ctx *ctx, int32_t width, int32_t root_height, int32_t max_cuts, int32_t max_nodes,
                                  yalps_batch **out) {
@@ -1276,25 +1312,19 @@ static int32_t batch_create_impl(yalps_ctx *ctx, int32_t width, int32_t root_hei
     HIP_TRY(hipMalloc(&b->root_pos, sizeof(int32_t) * (size_t)(width + d.h0)));
     HIP_TRY(hipMalloc(&b->root_var, sizeof(int32_t) * (size_t)(width + d.h0)));
     HIP_TRY(hipMalloc(&d.ws_mat, sizeof(double) * nm * d.hmax * d.pitch));
-    HIP_TRY(hipMalloc(&d.ws_rhs, sizeof(double) * nm * d.hmax));
-    HIP_TRY(hipMalloc(&d.ws_pos, sizeof(int32_t) * nm * d.permmax));
-    HIP_TRY(hipMalloc(&d.ws_var, sizeof(int32_t) * nm * d.permmax));
-    HIP_TRY(hipMalloc(&b->cut_off, sizeof(int32_t) * (nm + 1)));
-    HIP_TRY(hipMalloc(&b->cut_sign, sizeof(int32_t) * nm * max_cuts));
-    HIP_TRY(hipMalloc(&b->cut_var, sizeof(int32_t) * nm * max_cuts));
-    HIP_TRY(hipMalloc(&b->cut_val, sizeof(double) * nm * max_cuts));
-    HIP_TRY(hipMalloc(&d.status, sizeof(int32_t) * nm));
+    // inputs (cut lists) and outputs (status, result, column 0, permutations of every node) each in ONE block, so
+    // that a batch costs one copy up and one copy down (batch_solve_fetch lays them out tightly per batch)
+    b->in_bytes = sizeof(int32_t) * (nm + 1) + 16 * nm * (size_t)max_cuts + 64;
+    b->out_bytes = nm * (sizeof(int32_t) + sizeof(double) + sizeof(double) * d.hmax + 2 * sizeof(int32_t) * d.permmax) + 64;
+    HIP_TRY(hipMalloc(&b->in_block, b->in_bytes));
+    HIP_TRY(hipMalloc(&b->out_block, b->out_bytes));
+    batch_layout(b, max_nodes, max_nodes * max_cuts);
     HIP_TRY(hipMalloc(&d.height, sizeof(int32_t) * nm));
-    HIP_TRY(hipMalloc(&d.result, sizeof(double) * nm));
     HIP_TRY(hipMalloc(&d.pivots, sizeof(long long) * nm));
     d.root_mat = b->root_mat;
     d.root_rhs = b->root_rhs;
     d.root_pos = b->root_pos;
     d.root_var = b->root_var;
-    d.cut_off = b->cut_off;
-    d.cut_sign = b->cut_sign;
-    d.cut_var = b->cut_var;
-    d.cut_val = b->cut_val;
     if (b->shmem > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(b->lds ? reinterpret_cast<const void *>(batch_kernel<256, true>)
                                            : reinterpret_cast<const void *>(batch_kernel<1024, false>),
@@ -1322,8 +1352,7 @@ void yalps_batch_destroy(yalps_batch *b) {
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
-    void *bufs[] = {b->root_mat, b->root_rhs, b->root_pos, b->root_var, b->d.ws_mat, b->d.ws_rhs, b->d.ws_pos, b->d.ws_var,
-                    b->cut_off, b->cut_sign, b->cut_var, b->cut_val, b->d.status, b->d.height, b->d.result, b->d.pivots};
+    void *bufs[] = {b->root_mat, b->root_rhs, b->root_pos, b->root_var, b->d.ws_mat, b->in_block, b->out_block, b->d.height, b->d.pivots};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (b->pin) (void)hipHostFree(b->pin);
@@ -1357,6 +1386,7 @@ int32_t yalps_batch_solve(yalps_batch *b, int32_t count, const int32_t *cut_offs
     yalps_ctx *c = b->ctx;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = c->stream;
+    batch_layout(b, (size_t)b->max_nodes, (size_t)b->max_nodes * b->max_cuts); // (the capacity layout)
     HIP_TRY(hipMemcpyAsync(b->cut_off, cut_offsets, sizeof(int32_t) * (size_t)(count + 1), hipMemcpyHostToDevice, s));
     if (total > 0) {
         HIP_TRY(hipMemcpyAsync(b->cut_sign, cut_sign, sizeof(int32_t) * (size_t)total, hipMemcpyHostToDevice, s));
@@ -1393,9 +1423,8 @@ static int32_t batch_solve_fetch(yalps_batch *b, int32_t count, const int32_t *o
     hipStream_t s = c->stream;
     const BatchDesc &d = b->d;
     const size_t total = (size_t)off[count], n = (size_t)count;
-    const size_t in_off = 0, in_sign = in_off + 4 * (n + 1), in_var = in_sign + 4 * total, in_val = (in_var + 4 * total + 7) & ~(size_t)7;
-    const size_t out_st = in_val + 8 * total, out_res = (out_st + 4 * n + 7) & ~(size_t)7, out_col0 = out_res + 8 * n;
-    const size_t out_pos = out_col0 + 8 * n * d.hmax, out_var = out_pos + 4 * n * d.permmax, bytes = out_var + 4 * n * d.permmax;
+    batch_layout(b, n, total); // tight: one copy up, one copy down
+    const size_t bytes = b->lay_in_total + b->lay_out_total;
     if (bytes > b->pin_bytes) {
         if (b->pin) HIP_TRY(hipHostFree(b->pin));
         b->pin = nullptr;
@@ -1403,17 +1432,12 @@ static int32_t batch_solve_fetch(yalps_batch *b, int32_t count, const int32_t *o
         HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&b->pin), 2 * bytes, hipHostMallocDefault));
         b->pin_bytes = 2 * bytes;
     }
-    char *p = b->pin;
-    std::memcpy(p + in_off, off, 4 * (n + 1));
-    std::memcpy(p + in_sign, sign, 4 * total);
-    std::memcpy(p + in_var, var, 4 * total);
-    std::memcpy(p + in_val, val, 8 * total);
-    HIP_TRY(hipMemcpyAsync(b->cut_off, p + in_off, 4 * (n + 1), hipMemcpyHostToDevice, s));
-    if (total > 0) {
-        HIP_TRY(hipMemcpyAsync(b->cut_sign, p + in_sign, 4 * total, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(b->cut_var, p + in_var, 4 * total, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(b->cut_val, p + in_val, 8 * total, hipMemcpyHostToDevice, s));
-    }
+    char *pin_in = b->pin, *pin_out = b->pin + b->lay_in_total;
+    std::memcpy(pin_in + b->lay_in[0], val, 8 * total);
+    std::memcpy(pin_in + b->lay_in[1], off, 4 * (n + 1));
+    std::memcpy(pin_in + b->lay_in[2], sign, 4 * total);
+    std::memcpy(pin_in + b->lay_in[3], var, 4 * total);
+    HIP_TRY(hipMemcpyAsync(b->in_block, pin_in, b->lay_in_total, hipMemcpyHostToDevice, s));
     b->d.precision = precision;
     b->d.max_pivots = maxPivots;
     if (b->lds)
@@ -1421,17 +1445,13 @@ static int32_t batch_solve_fetch(yalps_batch *b, int32_t count, const int32_t *o
     else
         batch_kernel<1024, false><<<dim3(count), dim3(1024), b->shmem, s>>>(b->d);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(p + out_st, d.status, 4 * n, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(p + out_res, d.result, 8 * n, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(p + out_col0, d.ws_rhs, 8 * n * d.hmax, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(p + out_pos, d.ws_pos, 4 * n * d.permmax, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(p + out_var, d.ws_var, 4 * n * d.permmax, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(pin_out, b->out_block, b->lay_out_total, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    std::memcpy(status_out, p + out_st, 4 * n);
-    std::memcpy(result_out, p + out_res, 8 * n);
-    std::memcpy(col0_all, p + out_col0, 8 * n * d.hmax);
-    std::memcpy(pos_all, p + out_pos, 4 * n * d.permmax);
-    std::memcpy(var_all, p + out_var, 4 * n * d.permmax);
+    std::memcpy(result_out, pin_out + b->lay_out[0], 8 * n);
+    std::memcpy(col0_all, pin_out + b->lay_out[1], 8 * n * d.hmax);
+    std::memcpy(status_out, pin_out + b->lay_out[2], 4 * n);
+    std::memcpy(pos_all, pin_out + b->lay_out[3], 4 * n * d.permmax);
+    std::memcpy(var_all, pin_out + b->lay_out[4], 4 * n * d.permmax);
     b->last_count = count;
     return 0;
 }
