@@ -21,6 +21,11 @@
  *                       out-of-band channel; text via yalps_last_error().
  * There is NO CPU fallback: without a usable gfx950 device every entry point
  * fails with YALPS_E_DEVICE.
+ *
+ * Threads: the host-array entry points (yalps_simplex_f64[_ex], yalps_simplex_sparse_f64, yalps_milp_f64) share one
+ * process-wide context and serialise on one mutex.  A yalps_ctx and the objects created from it belong to one thread
+ * at a time (their calls enqueue on the context's stream and share its scratch); different contexts are independent.
+ * yalps_last_error() is per thread.
  */
 #ifndef YALPS_HIP_H
 #define YALPS_HIP_H
