@@ -534,7 +534,8 @@ def test_inplace_path_check_cycles(nat, ctx, oracle):
 @pytest.mark.parametrize("M,N", [(1400, 8000), (300, 16000)])
 def test_check_cycles_on_wide_tableaux_launch_per_pivot(nat, ctx, M, N):
     """checkCycles where no persistent kernel applies (4098+ columns beyond the on-chip size): DECIDE launches of
-    pivot_kernel<1024,4|8,..> + APPLY launches of wide_kernel, 40 pivots against the numpy restatement (which
+    pivot_kernel<1024,4,..> + APPLY launches of wide_kernel, or (8194+ columns) the any-shape pair; 40 pivots
+    against the numpy restatement (which
     has no hasCycle: no cycle can close within 40 pivots of these LPs, the check only has to stay silent)."""
     from tests import _np_simplex as NP
     w, h = N + 1, M + 1
@@ -547,7 +548,7 @@ def test_check_cycles_on_wide_tableaux_launch_per_pivot(nat, ctx, M, N):
     try:
         t.upload(m, h, pos, var)
         status, result, npiv, _ = t.solve(max_pivots=40, check_cycles=True)
-        assert t.info()["last_path"] == "streaming", t.info()
+        assert t.info()["last_path"] == ("generic" if N > 8192 else "streaming"), t.info()
         got, gpos, gvar = t.download()
     finally:
         t.close()

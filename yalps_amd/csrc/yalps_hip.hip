@@ -174,6 +174,8 @@ struct yalps_tableau {
     int32_t height = 0;
     int cur = 0; // tableau buffer holding the current tableau
     bool generic = false; // no tuned kernel spans this shape: generic_decide_kernel / generic_apply_kernel (in place)
+    bool prefer_generic = false; // 8194..16385 columns, unsharded: the any-shape pair is on par with wide_kernel<1024,8>
+                                 // on dense tableaux (60 vs 74 us/pivot at 1025x16385, 130 vs 126 at 4097x9001) and skips untouched rows
     int shard_parity = 0;
     RVariant rvar{0, 0, 0, nullptr}; // resident kernel variant, fn == nullptr: tableau does not fit
     void *rc_sync = nullptr; // flags[2], verdict[2], error word of the persistent kernels (one allocation)
@@ -425,6 +427,7 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
         J = 8;
     }
     if (env_int("YALPS_HIP_GENERIC", 0)) t->generic = true; // (test hook: any shape through the any-shape pair)
+    t->prefer_generic = J == 8 && !env_int("YALPS_HIP_WIDE8", 0);
     const int forceR = env_int("YALPS_HIP_ROWS", 0);
     // spread the rows over all workgroups; rows in flight per lane R >= rows per workgroup if any
     // variant allows it (one batch per launch), else the largest R (several batches)
@@ -468,7 +471,7 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
         HIP_TRY(hipMemsetAsync(d.mat[k], 0, mat_bytes, s));
         HIP_TRY(hipMalloc(&d.rhs[k], sizeof(double) * (size_t)hcap));
     }
-    if (t->generic) {
+    if (t->generic || t->prefer_generic) {
         HIP_TRY(hipMalloc(&d.gen_prow, sizeof(double) * (size_t)d.pitch));
         HIP_TRY(hipMalloc(&d.gen_scal, sizeof(double) * 4));
     }
@@ -919,7 +922,8 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
         t->last_launches = 1;
         return run_small(c, sd, checkCycles, result_out, pivots_out, gpu_ms_out);
     }
-    if (t->generic) return solve_generic(t, precision, maxPivots, checkCycles, result_out, pivots_out, gpu_ms_out);
+    if (t->generic || (t->prefer_generic && t->d.nshards == 1))
+        return solve_generic(t, precision, maxPivots, checkCycles, result_out, pivots_out, gpu_ms_out);
     const int which = checkCycles ? 1 : 0;
     int rc = init_state(t, precision, maxPivots, checkCycles, false);
     if (rc) return rc;
