@@ -395,12 +395,74 @@ def test_resident_variants_match_oracle(nat, ctx, oracle, M, N, kernel):
     assert np.array_equal(gpos, rpos) and np.array_equal(gvar, rvar)
 
 
+# ---- resident kernel with rows parked in LDS (tableaux a little beyond the register files) --------
+@pytest.mark.parametrize("M,N,kernel,lds_rows", [
+    (2800, 3300, "resident_kernel<512,4,7,lds>", 4), (11000, 900, "resident_kernel<512,1,38,lds>", 5),
+    (3072, 3072, "resident_kernel<512,3,11,lds>", 2), (4300, 2040, "resident_kernel<512,2,16,lds>", 1),
+    (1700, 4300, "resident_kernel<512,5,5,lds>", 2), (1200, 5800, "resident_kernel<512,6,3,lds>", 2)])
+def test_resident_lds_rows_match_restatement(nat, ctx, M, N, kernel, lds_rows):
+    """Tableaux with more rows per workgroup than any register variant holds: the missing rows live in LDS.
+    100 pivots (phase 1 first, exact zeros in the data) against the pinned numpy restatement, bit for bit."""
+    from tests import _np_simplex as NP
+    w, h = N + 1, M + 1
+    m = nat.dense_lp(M, N, 13)
+    m.reshape(h, w)[h // 3] *= -1.0
+    m.reshape(h, w)[5::7, 3::5] = 0.0
+    pos, var = np.arange(w + h, dtype=np.int32), np.arange(w + h, dtype=np.int32)
+    ref, rpos, rvar = m.copy(), pos.copy(), var.copy()
+    est, eres, epiv = NP.simplex(ref, w, h, rpos, rvar, max_pivots=100)
+    t = nat.DeviceTableau(ctx, w, h)
+    try:
+        t.upload(m, h, pos, var)
+        status, result, npiv, _ = t.solve(max_pivots=100)
+        info = t.info()
+        got, gpos, gvar = t.download()
+    finally:
+        t.close()
+    assert info["last_path"] == "resident" and info["resident"].startswith(kernel), info
+    assert info["lds_rows"] == str(lds_rows), info
+    assert (status, npiv) == (est, epiv) and G.same_number(result, eres)
+    assert np.array_equal(gpos, rpos) and np.array_equal(gvar, rvar)
+    assert np.array_equal(got.view(np.int64), ref.view(np.int64))
+
+
+@pytest.mark.parametrize("variant,M,N", [("512,2,16", 256 * 17 + 40, 60), ("512,1,38", 256 * 42 - 3, 33), ("512,3,11", 256 * 19 - 1, 70),
+                                         ("512,6,3", 256 * 10, 25), ("512,4,7", 256 * 8 + 1, 48)])
+@pytest.mark.parametrize("check", [False, True])
+def test_resident_lds_rows_whole_solves(nat, ctx, oracle, monkeypatch, variant, M, N, check):
+    """Every LDS-row variant forced onto tall, narrow LPs (cheap for the oracle): whole solves -- phase 1, phase 2, the
+    pivot row / the candidate row / the entering column falling on parked rows many times -- with and without hasCycle."""
+    monkeypatch.setenv("YALPS_HIP_RVARIANT", variant)
+    w, h = N + 1, M + 1
+    m = nat.dense_lp(M, N, 5)
+    mm = m.reshape(h, w)
+    mm[1::3, 0] *= -0.05  # negative right-hand sides: phase 1 runs for a while
+    mm[1::3, 1:] *= -1.0
+    mm[2::5, 2::3] = 0.0
+    pos, var = np.arange(w + h, dtype=np.int32), np.arange(w + h, dtype=np.int32)
+    ref, rpos, rvar = m.copy(), pos.copy(), var.copy()
+    est, eres, epiv, _ = oracle.simplex(ref, w, h, rpos, rvar, max_pivots=3000, check_cycles=check)
+    t = nat.DeviceTableau(ctx, w, h)
+    try:
+        t.upload(m, h, pos, var)
+        status, result, npiv, _ = t.solve(max_pivots=3000, check_cycles=check)
+        info = t.info()
+        got, gpos, gvar = t.download()
+    finally:
+        t.close()
+    assert info["last_path"] == "resident" and info["resident"].startswith("resident_kernel<%s,lds>" % variant), info
+    assert (status, npiv) == (est, epiv) and G.same_number(result, eres)
+    assert np.array_equal(gpos, rpos) and np.array_equal(gvar, rvar)
+    assert np.array_equal(got.view(np.int64), ref.view(np.int64))
+
+
 # ---- persistent in-place kernel (stream_kernel) for tableaux beyond the on-chip size ---------------
 @pytest.mark.parametrize("M,N,pivots", [(2800, 3300, 120), (1400, 8000, 80), (12000, 1500, 60), (11000, 900, 60), (12000, 400, 60)])
-def test_inplace_path_matches_restatement(nat, ctx, M, N, pivots):
+def test_inplace_path_matches_restatement(nat, ctx, monkeypatch, M, N, pivots):
     """Dense tableaux that do not fit the register-resident kernel: `pivots` pivots (phase 1 first)
     through stream_kernel, against the pinned numpy restatement, bit for bit."""
     from tests import _np_simplex as NP
+    monkeypatch.setenv("YALPS_HIP_LDS_ROWS", "0")  # (two of the shapes would fit with rows parked in LDS)
     w, h = N + 1, M + 1
     m = nat.dense_lp(M, N, 11)
     m.reshape(h, w)[h // 3] *= -1.0
@@ -443,9 +505,11 @@ def test_inplace_path_sparse_netlib_whole_solve(nat, ctx, oracle):
     assert np.array_equal(got.view(np.int64), ref.view(np.int64))
 
 
-def test_inplace_fallback_restores_the_tableau(oracle):
+@pytest.mark.parametrize("lds_rows,path", [("0", "inplace+streaming"), ("1", "resident+inplace")])
+def test_inplace_fallback_restores_the_tableau(oracle, lds_rows, path):
     """A failed hand-off leaves the in-place tableau half updated: the host restores the copy it made before
-    the launch and continues with the launch-per-pivot kernels (forced after two chunks of 30 pivots)."""
+    the launch and continues with the launch-per-pivot kernels (forced after two chunks of 30 pivots).  With rows
+    parked in LDS the same tableau is resident: its forced failure continues in place from the untouched buffer."""
     import subprocess
     import sys
     code = (
@@ -457,21 +521,27 @@ def test_inplace_fallback_restores_the_tableau(oracle):
         "ref, rp, rv = m.copy(), pos.copy(), var.copy(); e = NP.simplex(ref, w, h, rp, rv, max_pivots=100)\n"
         "ctx = n.Context(0); t = n.DeviceTableau(ctx, w, h); t.upload(m, h, pos, var)\n"
         "st, res, piv, _ = t.solve(max_pivots=100); info = t.info(); gm, gp, gv = t.download()\n"
-        "assert info['last_path'] == 'inplace+streaming', info\n"
+        "assert info['last_path'] == %r, info\n"
         "assert (st, piv) == (e[0], e[2]), (st, piv, e)\n"
         "assert np.array_equal(gm.view(np.int64), ref.view(np.int64)) and np.array_equal(gp, rp) and np.array_equal(gv, rv)\n"
-        "print('ok')\n" % ROOT)
-    env = dict(os.environ, YALPS_HIP_RESIDENT_CHUNK="30", YALPS_HIP_RESIDENT_FAULT="2")
+        "print('ok')\n" % (ROOT, path))
+    env = dict(os.environ, YALPS_HIP_RESIDENT_CHUNK="30", YALPS_HIP_RESIDENT_FAULT="2", YALPS_HIP_LDS_ROWS=lds_rows)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
 
 
+TALL = [("inplace", "0"), ("resident", "1")]  # 11001 rows: stream_kernel, or resident_kernel<512,1,38> + 5 rows per workgroup in LDS
+
+
+@pytest.mark.parametrize("path,lds_rows", TALL)
 @pytest.mark.parametrize("kind", ["unbounded", "infeasible", "optimal", "optimal-degenerate"])
-def test_inplace_path_terminal_statuses(nat, ctx, kind):
-    """stream_kernel's exits other than the pivot budget, on a tall narrow LP (11001 x 61: beyond the resident
-    variants) solved to the end: unbounded after 124 pivots (result = the column), infeasible after 41
-    phase-1 pivots, optimal, and optimal with every 10th right-hand side zero (ties, ratios <= precision)."""
+def test_inplace_path_terminal_statuses(nat, ctx, monkeypatch, kind, path, lds_rows):
+    """The persistent kernels' exits other than the pivot budget, on a tall narrow LP (11001 x 61: beyond the register
+    variants) solved to the end through stream_kernel and through the resident kernel with LDS rows: unbounded after
+    124 pivots (result = the column), infeasible after 41 phase-1 pivots, optimal, and optimal with every 10th
+    right-hand side zero (ties, ratios <= precision)."""
     from tests import _np_simplex as NP
+    monkeypatch.setenv("YALPS_HIP_LDS_ROWS", lds_rows)
     M, N = 11000, 60
     w, h = N + 1, M + 1
     m = nat.dense_lp(M, N, 21)
@@ -492,7 +562,7 @@ def test_inplace_path_terminal_statuses(nat, ctx, kind):
     try:
         t.upload(m, h, pos, var)
         status, result, npiv, _ = t.solve(max_pivots=np.inf)
-        assert t.info()["last_path"] == "inplace", t.info()
+        assert t.info()["last_path"] == path, t.info()
         got, gpos, gvar = t.download()
     finally:
         t.close()
@@ -501,10 +571,12 @@ def test_inplace_path_terminal_statuses(nat, ctx, kind):
     assert np.array_equal(got.view(np.int64), ref.view(np.int64))
 
 
-def test_inplace_path_check_cycles(nat, ctx, oracle):
-    """options.checkCycles through stream_kernel<.., true>: the tall narrow LP solved to optimality with the
-    verdict exchange in every pivot (no cycle), and a Chvatal-style cycling LP embedded in a tall tableau
-    (rows of zeros below it) that must stop "cycled" at the same pivot as the oracle."""
+@pytest.mark.parametrize("path,lds_rows", TALL)
+def test_inplace_path_check_cycles(nat, ctx, oracle, monkeypatch, path, lds_rows):
+    """options.checkCycles through stream_kernel<.., true> (and the resident kernel with LDS rows): the tall narrow LP
+    solved to optimality with the verdict exchange in every pivot (no cycle), and a Chvatal-style cycling LP embedded
+    in a tall tableau (rows of zeros below it) that must stop "cycled" at the same pivot as the oracle."""
+    monkeypatch.setenv("YALPS_HIP_LDS_ROWS", lds_rows)
     M, N = 11000, 60
     w, h = N + 1, M + 1
     m = nat.dense_lp(M, N, 21)
@@ -521,7 +593,7 @@ def test_inplace_path_check_cycles(nat, ctx, oracle):
         try:
             t.upload(matrix, height, pos, var)
             status, result, npiv, _ = t.solve(**opts)
-            assert t.info()["last_path"] == "inplace", t.info()
+            assert t.info()["last_path"] == path, t.info()
             got, gpos, gvar = t.download()
         finally:
             t.close()

@@ -7,7 +7,7 @@ from yalps_amd import _native as N
 
 shapes = [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:]] or [
     (32, 32), (64, 128), (128, 128), (256, 256), (512, 512), (1024, 1024), (1536, 1536), (2048, 2048), (2560, 2560),
-    (3072, 3072), (4096, 4096), (512, 4096), (4096, 512), (256, 8192), (1024, 16384)]
+    (3072, 3072), (3300, 3000), (11000, 900), (4096, 4096), (512, 4096), (4096, 512), (256, 8192), (1024, 16384)]
 ctx = N.Context(0)
 rows = []
 for M, Nn in shapes:

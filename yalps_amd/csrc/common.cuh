@@ -75,6 +75,8 @@ struct Desc {
     int32_t *rc_err;                // set when a workgroup gives up waiting (never expected)
     unsigned long long *rc_verdict; // [2] checkCycles: workgroup 0's verdict on the pivot of an epoch, (epoch << 32) | cycled
     int32_t perm_len;
+    int32_t extra;  // resident_kernel<.., true>: rows per workgroup parked in LDS (0: none)
+    int32_t xl_ofs; // ... and where they start in the dynamic LDS block, in int32 units (behind var[] / pos[] at capacity)
     // any-shape fallback (generic_kernels.cuh): the normalised pivot row [pitch] and {quotient, its RHS, RHS non-zero}
     double *gen_prow, *gen_scal;
 };

@@ -102,7 +102,11 @@ __device__ __forceinline__ void ld16_sc1(double2 (&out)[J], const double *base, 
     for (int j = 0; j < J; j++) out[j] = make_double2(t[j].x, t[j].y);
 }
 
-template <int T, int J, int R>
+// X = true: d.extra more rows per workgroup (slots R .. R + extra - 1, rows b + NB * slot like the others) are parked
+// in LDS behind the basis, for tableaux a little beyond the register files: same arithmetic, same order of decisions,
+// the rows are read and written with 16-byte ds accesses at the columns the lane also holds of the register rows.
+constexpr int XROWS = 8; // most LDS rows per workgroup
+template <int T, int J, int R, bool X = false>
 __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chunk) {
     __shared__ double sk[2][16];
     __shared__ int si[2][16];
@@ -110,7 +114,10 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
     __shared__ double sh_nq[R + 2];  // -coef/quotient per row (:36), for the objective row, 1/quotient (:25)
     __shared__ double sh_ck;         // my candidate for the next exchange: key, row, local slot
     __shared__ int sh_ci, sh_cg, sh_fail, sh_flag, sh_verdict;
-    extern __shared__ int sh_perm[]; // workgroup 0: var[perm_len] then pos[perm_len]
+    __shared__ double sh_xcf[X ? XROWS : 1]; // LDS rows: pivot-column entry (kept for the whole pivot: no registers to hold it),
+    __shared__ double sh_xnq[X ? XROWS : 1]; // -coef/quotient (:36),
+    __shared__ double sh_xla[X ? XROWS : 1]; // entering-column entry for the candidate
+    extern __shared__ int sh_perm[]; // workgroup 0: var[perm_len] then pos[perm_len]; X: then the parked rows
 
     const int tid = threadIdx.x, NB = d.nb, b = blockIdx.x;
     const YState *Sin = d.st + parity;
@@ -138,6 +145,8 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
         const int c0 = 2 * (tid + j * T);
         cofs[j] = c0 < pitch ? c0 : 0;
     }
+    const int E = X ? d.extra : 0;
+    double *const xl = reinterpret_cast<double *>(sh_perm + (X ? d.xl_ofs : 0)); // row slot R + e at xl + e * pitch
     // ---- load my rows, the objective replica, my rows' RHS (lane g), the basis (workgroup 0) ----
     double2 x[R][J], o[J];
 #pragma unroll
@@ -149,8 +158,19 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
 #pragma unroll
         for (int j = 0; j < J; j++) x[g][j] = *reinterpret_cast<const double2 *>(mr + cofs[j]);
     }
-    const int my_r = b + NB * tid; // lane g = tid < R owns the scalar side of row g
-    const bool my_live = tid < R && my_r < h;
+    if constexpr (X) {
+        for (int e = 0; e < E; e++) {
+            const int r = b + NB * (R + e);
+            const double *mr = matA + (size_t)(r < h ? r : b) * pitch;
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                const int c0 = 2 * (tid + j * T);
+                if (c0 < pitch) *reinterpret_cast<double2 *>(xl + e * pitch + c0) = *reinterpret_cast<const double2 *>(mr + c0);
+            }
+        }
+    }
+    const int my_r = b + NB * tid; // lane g = tid < R (+ E) owns the scalar side of row slot g
+    const bool my_live = tid < R + E && my_r < h;
     double my_rhs = rhsA[my_live ? my_r : 0];
     if (b == 0) {
         for (int i = tid; i < d.perm_len; i += T) {
@@ -194,7 +214,7 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
                     c.i = my_r;
                 }
             } else if (la > 0) {
-                const double value = sh_val[tid];
+                const double value = (X && tid >= R) ? sh_xla[tid - R] : sh_val[tid];
                 if (value > precision) {
                     const double ratio = my_rhs / value;
                     if (ratio < INFINITY) {
@@ -233,6 +253,16 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
                 }
             }
         }
+        if constexpr (X) {
+            if (cg >= R) { // the candidate row is a parked one
+                const double *src = xl + (cg - R) * pitch;
+#pragma unroll
+                for (int j = 0; j < J; j++) {
+                    const int c0 = 2 * (tid + j * T);
+                    if (c0 < pitch) st16_sc1(dst + c0, *reinterpret_cast<const double2 *>(src + c0));
+                }
+            }
+        }
         if (tid == cg) st_sc1(d.rc_key[par] + b, my_rhs); // the candidate row's RHS entry (lane cg)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains ...
         __syncthreads();                                  // ... before ONE lane raises the flag:
@@ -250,6 +280,8 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
                 for (int j = 0; j < J; j++)
                     if (j == ula / T) sh_val[g] = elem(x[g][j], ela);
         }
+        if constexpr (X)
+            if (la > 0 && tid < E) sh_xla[tid] = xl[tid * pitch + la - 1];
         __syncthreads();
     };
     int done = 0, term = RUNNING;
@@ -404,6 +436,8 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
                     sh_val[R + 1] = elem(pv[j], ecol);
                 }
         }
+        if constexpr (X)
+            if (tid < E) sh_xcf[tid] = xl[tid * pitch + col - 1]; // (the rows are complete: every wave has passed the gather's barrier)
         __syncthreads();
         const double q = sh_val[R + 1], coef0 = sh_val[R];
         double cf[R]; // uniform: pivot-column entry of each of my rows
@@ -425,12 +459,16 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
         const int lslot = owner == b ? row / NB : -1; // my register slot of the pivot row, if I own it
         // the R + 2 divisions of the pivot column (one per lane of wave 0, not R+2 per lane)
         if (tid < R + 2) sh_nq[tid] = tid == R + 1 ? 1.0 / q : -sh_val[tid] / q;
+        if constexpr (X)
+            if (tid >= R + 2 && tid < R + 2 + E) sh_xnq[tid - (R + 2)] = -sh_xcf[tid - (R + 2)] / q;
         if (my_live) { // RHS entry of my row (:33 at column 0)
             const double pn_rhs = nz_rhs ? rhs_row / q : 0.0;
             double my_coef = 0.0;
 #pragma unroll
             for (int g = 0; g < R; g++)
                 if (tid == g) my_coef = cf[g];
+            if constexpr (X)
+                if (tid >= R) my_coef = sh_xcf[tid - R];
             if (tid == lslot)
                 my_rhs = pn_rhs;
             else if (fabs(my_coef) > 1e-16 && nz_rhs) {
@@ -476,6 +514,37 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
                 }
             }
             }
+            if constexpr (X) {
+                for (int e = 0; e < E; e++) { // the parked rows: the same, through LDS
+                    const int g = R + e;
+                    if ((g == only) != only_it) continue;
+                    double *xr = xl + e * pitch;
+                    const double cfe = sh_xcf[e];
+                    if (g == lslot) {
+#pragma unroll
+                        for (int j = 0; j < J; j++) {
+                            const int c0 = 2 * (tid + j * T);
+                            double2 v = pv[j];
+                            if (tid == col_tid && j == col_j) v = with_elem(v, ecol, sh_nq[R + 1]); // :25
+                            if (c0 < pitch) *reinterpret_cast<double2 *>(xr + c0) = v;
+                        }
+                    } else if (b + NB * g < h && fabs(cfe) > 1e-16) { // :31
+#pragma unroll
+                        for (int j = 0; j < J; j++) {
+                            const int c0 = 2 * (tid + j * T);
+                            if (c0 < pitch) {
+                                double2 v = *reinterpret_cast<const double2 *>(xr + c0);
+                                const double px = cfe * pv[j].x, py = cfe * pv[j].y;
+                                const double nx = v.x - px, ny = v.y - py;
+                                v.x = (nzmask & (1u << (2 * j))) ? nx : v.x;
+                                v.y = (nzmask & (1u << (2 * j + 1))) ? ny : v.y;
+                                if (tid == col_tid && j == col_j) v = with_elem(v, ecol, sh_xnq[e]); // :36
+                                *reinterpret_cast<double2 *>(xr + c0) = v;
+                            }
+                        }
+                    }
+                }
+            }
         };
         iter += 1.0;
         pivots += 1;
@@ -506,6 +575,23 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
                                     }
                                 }
                                 sh_val[g] = v;
+                            }
+                            if constexpr (X) {
+                                for (int e = 0; e < E; e++) { // (the parked rows still hold their entries from before this pivot)
+                                    double v = xl[e * pitch + la - 1];
+                                    const double cfe = sh_xcf[e];
+                                    if (R + e == lslot)
+                                        v = la == col ? sh_nq[R + 1] : p;
+                                    else if (b + NB * (R + e) < h && fabs(cfe) > 1e-16) {
+                                        if (la == col)
+                                            v = sh_xnq[e];
+                                        else if (nz) {
+                                            const double prod = cfe * p;
+                                            v = v - prod;
+                                        }
+                                    }
+                                    sh_xla[e] = v;
+                                }
                             }
                         }
                 }
@@ -543,6 +629,18 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
             for (int j = 0; j < J; j++) {
                 const int c0 = 2 * (tid + j * T);
                 if (c0 < pitch) *reinterpret_cast<double2 *>(mr + c0) = x[g][j];
+            }
+        }
+    }
+    if constexpr (X) {
+        for (int e = 0; e < E; e++) {
+            const int r = b + NB * (R + e);
+            if (r < h) {
+#pragma unroll
+                for (int j = 0; j < J; j++) {
+                    const int c0 = 2 * (tid + j * T);
+                    if (c0 < pitch) *reinterpret_cast<double2 *>(matB + (size_t)r * pitch + c0) = *reinterpret_cast<const double2 *>(xl + e * pitch + c0);
+                }
             }
         }
     }

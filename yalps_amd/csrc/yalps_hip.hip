@@ -109,6 +109,15 @@ const RVariant kResident[] = {
     // tests/test_cabi_symbols.py checks the register counts of the built code object)
 };
 #undef RVARIANT
+// The same with up to XROWS more rows per workgroup parked in LDS (tableaux a little beyond the register files):
+// tried when no variant above fits; R = register rows, the LDS rows are what is missing.
+const RVariant kResidentLds[] = {
+    // (one register row less than the plain variants where those sit at the 256-VGPR cap: the LDS code needs a few)
+    {512, 1, 38, resident_kernel<512, 1, 38, true>}, {512, 2, 16, resident_kernel<512, 2, 16, true>},
+    {512, 3, 11, resident_kernel<512, 3, 11, true>}, {512, 4, 7, resident_kernel<512, 4, 7, true>},
+    {512, 5, 5, resident_kernel<512, 5, 5, true>},   {512, 6, 3, resident_kernel<512, 6, 3, true>},
+};
+constexpr size_t RESIDENT_LDS_BYTES = 160 * 1024 - 2048; // dynamic LDS of one workgroup per CU (the static part is < 2 KB)
 // stream_kernel<lanes, 16-byte units per lane and row>: same signature as the resident kernel
 const RVariant kStream[] = {
     {256, 1, 0, stream_kernel<256, 1, false>},   {256, 2, 0, stream_kernel<256, 2, false>},
@@ -188,6 +197,7 @@ struct yalps_tableau {
     int last_path = 0;               // what the last solve ran: 1 resident, 2 streaming, 4 small, 8 in place (sums: fallbacks)
     int64_t last_launches = 0;       // kernel launches of the last solve that did work (resident: chunks)
     size_t rshmem = 0;
+    size_t rx_shmem = 0; // resident kernel with LDS rows: its (fixed) dynamic LDS size
     int32_t *perm_backup = nullptr; // basis before the resident launch in flight (restored if it fails)
     int32_t perm_backup_len = 0;
     int32_t perm_len = 0; // entries of pos / var (width + GLOBAL height)
@@ -501,6 +511,22 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
                 t->rvar = v;
             }
         }
+        if (!t->rvar.fn && env_int("YALPS_HIP_LDS_ROWS", 1)) { // a little too tall: park the rows that are missing in LDS
+            const int xl_ofs = (2 * (width + hcap) + 3) / 4 * 4;
+            int best_extra = INT_MAX;
+            for (const RVariant &v : kResidentLds) {
+                const int extra = rows_per_block - v.R;
+                if (v.T * v.J < units || extra < 1 || extra > XROWS) continue;
+                if (fT && (v.T != fT || v.J != fJ || v.R != fR)) continue;
+                const size_t bytes = sizeof(int32_t) * (size_t)xl_ofs + sizeof(double) * (size_t)extra * d.pitch;
+                if (bytes > RESIDENT_LDS_BYTES || extra >= best_extra) continue;
+                best_extra = extra;
+                t->rvar = v;
+                t->rx_shmem = bytes;
+                d.extra = extra;
+                d.xl_ofs = xl_ofs;
+            }
+        }
     }
     // persistent in-place kernel for what does not fit on chip: lanes x units span the row, the normalised
     // pivot row + my rows' scalars fit in LDS
@@ -574,7 +600,8 @@ int32_t yalps_tableau_info(const yalps_tableau *t, char *buf, int32_t len) {
     if (!t || !buf || len < 1) return fail(YALPS_E_ARG, "yalps_tableau_info: bad argument");
     char res[96] = "none", inp[64] = "none";
     if (t->rvar.fn)
-        std::snprintf(res, sizeof res, "resident_kernel<%d,%d,%d> chunk=%d", t->rvar.T, t->rvar.J, t->rvar.R, RESIDENT_CHUNK);
+        std::snprintf(res, sizeof res, "resident_kernel<%d,%d,%d%s> chunk=%d lds_rows=%d", t->rvar.T, t->rvar.J, t->rvar.R,
+                      t->d.extra ? ",lds" : "", RESIDENT_CHUNK, t->d.extra);
     if (t->svar.fn) std::snprintf(inp, sizeof inp, "stream_kernel<%d,%d>", t->svar.T, t->svar.J);
     char str[64];
     if (t->wfn)
@@ -946,7 +973,7 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
         const bool in_place = use_stream;
         const RVariant &pv = in_place ? (checkCycles ? t->svar_check : t->svar) : t->rvar;
         bool &sattr = checkCycles ? t->sattr_check : t->sattr;
-        const size_t shmem = in_place ? t->sshmem : sizeof(int32_t) * 2 * (size_t)t->perm_len;
+        const size_t shmem = in_place ? t->sshmem : t->rx_shmem ? t->rx_shmem : sizeof(int32_t) * 2 * (size_t)t->perm_len;
         if (in_place ? !sattr : shmem != t->rshmem) {
             if (shmem > 48 * 1024)
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pv.fn), hipFuncAttributeMaxDynamicSharedMemorySize,
