@@ -58,9 +58,19 @@ def _kernel_metadata():
     with tempfile.TemporaryDirectory() as tmp:
         fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "dev.co")
         subprocess.run([f"{llvm}/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fat], check=True)
-        subprocess.run([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}",
-                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
-        notes = subprocess.run([f"{llvm}/llvm-readelf", "--notes", co], check=True, capture_output=True, text=True).stdout
+        # one bundle per translation unit (yalps_hip.hip + persistent_*.hip), back to back in the section
+        magic = b"__CLANG_OFFLOAD_BUNDLE__"
+        blob = open(fat, "rb").read()
+        starts = [i for i in range(len(blob)) if blob.startswith(magic, i)]
+        assert starts, "no offload bundle in .hip_fatbin"
+        notes = ""
+        for k, lo in enumerate(starts):
+            part = os.path.join(tmp, "part%d.bin" % k)
+            with open(part, "wb") as f:
+                f.write(blob[lo:starts[k + 1] if k + 1 < len(starts) else len(blob)])
+            subprocess.run([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={part}",
+                            "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
+            notes += subprocess.run([f"{llvm}/llvm-readelf", "--notes", co], check=True, capture_output=True, text=True).stdout
     kernels, cur = {}, {}
     for line in notes.splitlines():
         m = re.match(r"\s*(?:- )?\.(\w+):\s+(\S+)\s*$", line)

@@ -12,15 +12,20 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libyalps_hip.so")
-HIP_SRC = os.path.join(HERE, "csrc", "yalps_hip.hip")
-HIP_DEPS = [os.path.join(HERE, "csrc", f) for f in sorted(os.listdir(os.path.join(HERE, "csrc"))) if f.endswith((".cuh", ".inc"))]
+CSRC = os.path.join(HERE, "csrc")
+HIP_SRC = os.path.join(CSRC, "yalps_hip.hip")  # host side + C ABI + the launch-per-pivot / single-workgroup / batch kernels
+# the persistent kernels' instantiations, one translation unit per group: compiled side by side (the device compile of
+# ~40 register-heavy kernels in one unit took 2.5 minutes)
+HIP_UNITS = [HIP_SRC] + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.startswith("persistent_") and f.endswith(".hip")]
+HIP_DEPS = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".cuh", ".inc", ".h"))]
+OBJ_DIR = os.path.join(HERE, "build")
 HEADER = os.path.join(ROOT, "include", "yalps_hip.h")
 NAPI_SRC = os.path.join(HERE, "napi", "yalps_napi.cc")
 NAPI_OUT = os.path.join(HERE, "napi", "yalps_napi.node")
 
 # -ffp-contract=off: the reference (V8) rounds the product and the difference of
 # M[r,c] - coef*M[row,c] separately (src/simplex.ts:33); an fma would change pivot paths.
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
 
 
 def _stale(out, *srcs):
@@ -28,13 +33,29 @@ def _stale(out, *srcs):
 
 
 def build_hip(force=False, verbose=False):
-    if not force and not _stale(LIB, HIP_SRC, HEADER, *HIP_DEPS):
+    if not force and not _stale(LIB, HEADER, *HIP_UNITS, *HIP_DEPS):
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, *HIPCC_FLAGS, "-o", LIB, HIP_SRC]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    objs = [os.path.join(OBJ_DIR, os.path.basename(u)[:-4] + ".o") for u in HIP_UNITS]
+
+    def compile_unit(pair):
+        unit, obj = pair
+        if not force and not _stale(obj, unit, HEADER, *HIP_DEPS):
+            return
+        cmd = [hipcc, *HIPCC_FLAGS, "-c", "-o", obj, unit]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(len(objs), os.cpu_count() or 1)) as pool:
+        list(pool.map(compile_unit, zip(HIP_UNITS, objs)))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp", *objs]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    os.replace(LIB + ".tmp", LIB)  # (never a half-written library under the final name)
     return LIB
 
 

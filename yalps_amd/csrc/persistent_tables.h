@@ -1,0 +1,24 @@
+// persistent_tables.h -- the instantiations of the persistent kernels (resident_kernel.cuh, stream_kernel.cuh) are
+// compiled in translation units of their own (persistent_*.hip: the build compiles them side by side); the host
+// side (yalps_hip.hip) sees them through these tables.  A kernel is passed as the address of its host stub: every
+// translation unit includes common.cuh inside its own unnamed namespace, so `Desc` is formally a different (identical)
+// type in each, and the host casts the address back to void (*)(Desc, int parity, int chunk) before the launch.
+#pragma once
+
+struct PersistentEntry {
+    int T, J, R;    // lanes, 16-byte units per lane and row, rows per workgroup in registers (stream_kernel: 0)
+    const void *fn; // __global__ void (Desc, int, int)
+};
+struct PersistentTable {
+    const PersistentEntry *entries;
+    int count;
+};
+// resident_kernel<T, J, R>: tableau in the register files
+PersistentTable yalps_resident_table_a();
+PersistentTable yalps_resident_table_b();
+// resident_kernel<T, J, R, true>: up to XROWS more rows per workgroup parked in LDS
+PersistentTable yalps_resident_lds_table();
+constexpr int YALPS_RESIDENT_LDS_MAX_ROWS = 8;
+// stream_kernel<T, J, false> / <T, J, true> (with hasCycle): persistent, in place
+PersistentTable yalps_stream_table();
+PersistentTable yalps_stream_check_table();

@@ -42,6 +42,7 @@
 #include <vector>
 
 #include "../../include/yalps_hip.h"
+#include "persistent_tables.h"
 
 #pragma clang fp contract(off)
 
@@ -52,8 +53,6 @@ namespace {
 #include "wide_kernel.cuh"
 #include "shard_kernels.cuh"
 #include "assemble_kernels.cuh"
-#include "resident_kernel.cuh"
-#include "stream_kernel.cuh"
 #include "generic_kernels.cuh"
 #include "wg_simplex.cuh"
 #include "batch_kernel.cuh"
@@ -90,46 +89,27 @@ struct RVariant {
     int T, J, R;
     ResidentFn fn;
 };
-#define RVARIANT(T, J, R) {T, J, R, resident_kernel<T, J, R>}
-const RVariant kResident[] = {
-    // few, fat lanes: the loop is latency-bound, and <= 8 waves per CU leave each lane 256 VGPRs.
-    // A tableau takes the feasible variant (T * J 16-byte units span a row, R rows per workgroup) with
-    // the fewest row registers J * R; J = 3 / 5 keep 1025..1536 / 2049..2560 units out of the next power of two.
-    RVARIANT(256, 1, 4), RVARIANT(256, 1, 9), RVARIANT(256, 1, 16),
-    RVARIANT(256, 2, 4), RVARIANT(256, 2, 9),
-    RVARIANT(512, 1, 24), RVARIANT(512, 1, 32), RVARIANT(512, 1, 40), // tall and narrow: 17..40 rows per workgroup
-    RVARIANT(512, 2, 4), RVARIANT(512, 2, 6), RVARIANT(512, 2, 9), RVARIANT(512, 2, 12), RVARIANT(512, 2, 16),
-    RVARIANT(512, 3, 4), RVARIANT(512, 3, 6), RVARIANT(512, 3, 9), RVARIANT(512, 3, 12),
-    RVARIANT(512, 4, 4), RVARIANT(512, 4, 6), RVARIANT(512, 4, 8), // (<512,4,9> spills one VGPR on top of 119 SGPRs)
-    RVARIANT(512, 5, 4), RVARIANT(512, 5, 6),
-    RVARIANT(512, 6, 4),
-    // (<1024,1,9> fits its 128 VGPRs now but is no faster at 2049^2: 6.94 against 6.82 us/pivot)
-    // (no variant may need AGPRs -- <256,1,32> (374 registers) left its last row slots unwritten on the
-    // GPU -- or scratch: SGPR spills that end up in scratch computed garbage in stream_kernel<1024,8>;
-    // tests/test_cabi_symbols.py checks the register counts of the built code object)
-};
-#undef RVARIANT
+// The persistent kernels' instantiations live in translation units of their own (persistent_*.hip, compiled side by
+// side; persistent_tables.h).  A tableau takes the feasible resident variant (T * J 16-byte units span a row, R rows
+// per workgroup) with the fewest row registers J * R -- few, fat lanes: the loop is latency-bound, and <= 8 waves per
+// CU leave each lane 256 VGPRs; J = 3 / 5 keep 1025..1536 / 2049..2560 units out of the next power of two.
+std::vector<RVariant> variants_of(std::initializer_list<PersistentTable> tables) {
+    std::vector<RVariant> out;
+    for (const PersistentTable &t : tables)
+        for (int i = 0; i < t.count; i++)
+            out.push_back({t.entries[i].T, t.entries[i].J, t.entries[i].R,
+                           reinterpret_cast<ResidentFn>(const_cast<void *>(t.entries[i].fn))});
+    return out;
+}
+const std::vector<RVariant> kResident = variants_of({yalps_resident_table_a(), yalps_resident_table_b()});
 // The same with up to XROWS more rows per workgroup parked in LDS (tableaux a little beyond the register files):
 // tried when no variant above fits; R = register rows, the LDS rows are what is missing.
-const RVariant kResidentLds[] = {
-    // (one register row less than the plain variants where those sit at the 256-VGPR cap: the LDS code needs a few)
-    {512, 1, 38, resident_kernel<512, 1, 38, true>}, {512, 2, 16, resident_kernel<512, 2, 16, true>},
-    {512, 3, 11, resident_kernel<512, 3, 11, true>}, {512, 4, 7, resident_kernel<512, 4, 7, true>},
-    {512, 5, 5, resident_kernel<512, 5, 5, true>},   {512, 6, 3, resident_kernel<512, 6, 3, true>},
-};
+const std::vector<RVariant> kResidentLds = variants_of({yalps_resident_lds_table()});
+constexpr int XROWS = YALPS_RESIDENT_LDS_MAX_ROWS;
 constexpr size_t RESIDENT_LDS_BYTES = 160 * 1024 - 2048; // dynamic LDS of one workgroup per CU (the static part is < 2 KB)
-// stream_kernel<lanes, 16-byte units per lane and row>: same signature as the resident kernel
-const RVariant kStream[] = {
-    {256, 1, 0, stream_kernel<256, 1, false>},   {256, 2, 0, stream_kernel<256, 2, false>},
-    {1024, 1, 0, stream_kernel<1024, 1, false>}, {1024, 2, 0, stream_kernel<1024, 2, false>},
-    {1024, 4, 0, stream_kernel<1024, 4, false>},
-    // (<1024,8> needs 77 VGPR + 118 SGPR spills at the 128-register cap and computed garbage on the GPU: rows wider
-    // than 8193 columns stay with wide_kernel)
-};
-const RVariant kStreamCheck[] = { // checkCycles (<1024,4,true> would spill: those tableaux keep DECIDE + APPLY launches)
-    {256, 1, 0, stream_kernel<256, 1, true>},   {256, 2, 0, stream_kernel<256, 2, true>},
-    {1024, 1, 0, stream_kernel<1024, 1, true>}, {1024, 2, 0, stream_kernel<1024, 2, true>},
-};
+// stream_kernel<lanes, 16-byte units per lane and row, hasCycle>: same signature as the resident kernel
+const std::vector<RVariant> kStream = variants_of({yalps_stream_table()});
+const std::vector<RVariant> kStreamCheck = variants_of({yalps_stream_check_table()});
 constexpr int RESIDENT_CHUNK = 4096; // pivots per launch of the resident kernel (bounds its run time)
 
 thread_local std::string g_err;
