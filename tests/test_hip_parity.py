@@ -505,6 +505,37 @@ def test_inplace_path_sparse_netlib_whole_solve(nat, ctx, oracle):
     assert np.array_equal(got.view(np.int64), ref.view(np.int64))
 
 
+def test_two_tableaux_share_a_kernel_with_different_lds_needs(nat, ctx):
+    """The >48 KB dynamic-LDS permission belongs to the kernel function, not to a tableau: A (65.6 KB of LDS in
+    stream_kernel<1024,4>), then B (49.7 KB, same function), then A again -- the second tableau must not lower what the
+    first one is allowed to launch with."""
+    from tests import _np_simplex as NP
+    runs = []
+    tabs = []
+    try:
+        for M, N in ((256, 8192), (299, 6200)):
+            w, h = N + 1, M + 1
+            m = nat.dense_lp(M, N, 3)
+            pos = np.arange(w + h, dtype=np.int32)
+            t = nat.DeviceTableau(ctx, w, h)
+            tabs.append((t, m, w, h, pos))
+        for k in (0, 1, 0):
+            t, m, w, h, pos = tabs[k]
+            t.upload(m, h, pos, pos.copy())
+            st, res, piv, _ = t.solve(max_pivots=20)
+            assert t.info()["last_path"] == "inplace" and t.info()["inplace"] == "stream_kernel<1024,4>", t.info()
+            runs.append((k, st, res, piv, t.download()))
+    finally:
+        for t, *_ in tabs:
+            t.close()
+    for k, st, res, piv, (gm, gp, gv) in runs:
+        _, m, w, h, pos = tabs[k]
+        ref, rp, rv = m.copy(), pos.copy(), pos.copy()
+        est, eres, epiv = NP.simplex(ref, w, h, rp, rv, max_pivots=20)
+        assert (st, piv) == (est, epiv) and G.same_number(res, eres)
+        assert np.array_equal(gm.view(np.int64), ref.view(np.int64)) and np.array_equal(gp, rp) and np.array_equal(gv, rv)
+
+
 @pytest.mark.parametrize("lds_rows,path", [("0", "inplace+streaming"), ("1", "resident+inplace")])
 def test_inplace_fallback_restores_the_tableau(oracle, lds_rows, path):
     """A failed hand-off leaves the in-place tableau half updated: the host restores the copy it made before

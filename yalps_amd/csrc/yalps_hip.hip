@@ -106,7 +106,6 @@ const std::vector<RVariant> kResident = variants_of({yalps_resident_table_a(), y
 // tried when no variant above fits; R = register rows, the LDS rows are what is missing.
 const std::vector<RVariant> kResidentLds = variants_of({yalps_resident_lds_table()});
 constexpr int XROWS = YALPS_RESIDENT_LDS_MAX_ROWS;
-constexpr size_t RESIDENT_LDS_BYTES = 160 * 1024 - 2048; // dynamic LDS of one workgroup per CU (the static part is < 2 KB)
 // stream_kernel<lanes, 16-byte units per lane and row, hasCycle>: same signature as the resident kernel
 const std::vector<RVariant> kStream = variants_of({yalps_stream_table()});
 const std::vector<RVariant> kStreamCheck = variants_of({yalps_stream_check_table()});
@@ -117,6 +116,22 @@ thread_local std::string g_err;
 int fail(int code, const std::string &msg) {
     g_err = msg;
     return code;
+}
+
+// Dynamic LDS beyond 48 KB needs the function attribute raised first.  The attribute belongs to the FUNCTION (per device),
+// not to a launch: raised once to the most a workgroup can have (one workgroup per CU; every kernel's static part is
+// below 2 KB), never to the size one tableau happens to need -- a second tableau with a smaller need would lower it
+// under the first one's feet.
+constexpr size_t LDS_DYNAMIC_MAX = 160 * 1024 - 2048;
+int allow_big_lds(int device, const void *fn) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void *>> done;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({device, fn})) return 0;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_DYNAMIC_MAX);
+    if (e != hipSuccess) return fail(YALPS_E_DEVICE, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e));
+    done.insert({device, fn});
+    return 0;
 }
 
 #define HIP_TRY(expr)                                                                             \
@@ -438,8 +453,7 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
         t->wshmem = sizeof(double) * ((size_t)((n + 15) / 16 * 16 < 16 ? 16 : (n + 15) / 16 * 16) + 2 * (size_t)rows_per_block);
         if (t->wshmem > 150 * 1024) t->generic = true; // (pivot row + per-row scalars exceed LDS)
         if (!t->generic && t->wshmem > 48 * 1024)
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(t->wfn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)t->wshmem));
+            if (int rc = allow_big_lds(ctx->device, reinterpret_cast<const void *>(t->wfn))) return rc;
     }
 
     Desc &d = t->d;
@@ -499,7 +513,7 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
                 if (v.T * v.J < units || extra < 1 || extra > XROWS) continue;
                 if (fT && (v.T != fT || v.J != fJ || v.R != fR)) continue;
                 const size_t bytes = sizeof(int32_t) * (size_t)xl_ofs + sizeof(double) * (size_t)extra * d.pitch;
-                if (bytes > RESIDENT_LDS_BYTES || extra >= best_extra) continue;
+                if (bytes > LDS_DYNAMIC_MAX || extra >= best_extra) continue;
                 best_extra = extra;
                 t->rvar = v;
                 t->rx_shmem = bytes;
@@ -810,8 +824,7 @@ static int32_t solve_generic(yalps_tableau *t, double precision, double maxPivot
     const size_t shmem = sizeof(double) * (size_t)rpw;
     if (shmem > 150 * 1024) return fail(YALPS_E_ARG, "tableau too tall for this build");
     if (shmem > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(generic_apply_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)shmem));
+        if (int rc = allow_big_lds(c->device, reinterpret_cast<const void *>(generic_apply_kernel))) return rc;
     constexpr int PAIRS = 32;
     if (gpu_ms_out) HIP_TRY(hipEventRecord(c->ev0, s));
     t->last_path = 16;
@@ -956,8 +969,7 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
         const size_t shmem = in_place ? t->sshmem : t->rx_shmem ? t->rx_shmem : sizeof(int32_t) * 2 * (size_t)t->perm_len;
         if (in_place ? !sattr : shmem != t->rshmem) {
             if (shmem > 48 * 1024)
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pv.fn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)shmem));
+                if (int rc2 = allow_big_lds(c->device, reinterpret_cast<const void *>(pv.fn))) return rc2;
             if (in_place)
                 sattr = true;
             else
@@ -1337,9 +1349,9 @@ static int32_t batch_create_impl(yalps_ctx *ctx, int32_t width, int32_t root_hei
     d.root_pos = b->root_pos;
     d.root_var = b->root_var;
     if (b->shmem > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute(b->lds ? reinterpret_cast<const void *>(batch_kernel<256, true>)
-                                           : reinterpret_cast<const void *>(batch_kernel<1024, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->shmem));
+        if (int rc = allow_big_lds(ctx->device, b->lds ? reinterpret_cast<const void *>(batch_kernel<256, true>)
+                                                       : reinterpret_cast<const void *>(batch_kernel<1024, false>)))
+            return rc;
     *out = b;
     return 0;
 }
