@@ -24,7 +24,8 @@
  *
  * Threads: the host-array entry points (yalps_simplex_f64[_ex], yalps_simplex_sparse_f64, yalps_milp_f64) share one
  * process-wide context and serialise on one mutex.  A yalps_ctx and the objects created from it belong to one thread
- * at a time (their calls enqueue on the context's stream and share its scratch); different contexts are independent.
+ * at a time (their calls enqueue on the context's stream and share its scratch); different contexts are independent
+ * (solves that use the whole chip in one persistent launch take turns per device inside the library).
  * yalps_last_error() is per thread.
  */
 #ifndef YALPS_HIP_H

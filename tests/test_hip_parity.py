@@ -505,6 +505,45 @@ def test_inplace_path_sparse_netlib_whole_solve(nat, ctx, oracle):
     assert np.array_equal(got.view(np.int64), ref.view(np.int64))
 
 
+def test_two_contexts_solve_concurrently_from_two_threads(nat, oracle):
+    """Two contexts on one device, one thread each (ctypes releases the GIL during a solve): whole-chip persistent
+    launches take turns inside the library, nobody falls off the resident path, both get the oracle's answer."""
+    import threading
+    M = 1024
+    w = h = M + 1
+    m = nat.dense_lp(M, M, 42)
+    pos = np.arange(w + h, dtype=np.int32)
+    ref, rp, rv = m.copy(), pos.copy(), pos.copy()
+    est, eres, epiv, _ = oracle.simplex(ref, w, h, rp, rv, max_pivots=np.inf)
+    out, errors = {}, []
+
+    def work(k):
+        try:
+            c = nat.Context(0)
+            t = nat.DeviceTableau(c, w, h)
+            try:
+                res = []
+                for _ in range(4):
+                    t.upload(m, h, pos, pos.copy())
+                    st, r, piv, _ms = t.solve(max_pivots=np.inf)
+                    res.append((st, r, piv, t.info()["last_path"]))
+                out[k] = (res, t.download())
+            finally:
+                t.close()
+                c.close()
+        except Exception as e:  # noqa: BLE001 (reported by the main thread)
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    [x.start() for x in threads]
+    [x.join() for x in threads]
+    assert not errors, errors
+    for k in range(2):
+        res, (gm, gp, gv) = out[k]
+        assert all(r[0] == est and G.same_number(r[1], eres) and r[2] == epiv and r[3] == "resident" for r in res), res
+        assert np.array_equal(gm.view(np.int64), ref.view(np.int64)) and np.array_equal(gp, rp) and np.array_equal(gv, rv)
+
+
 def test_two_tableaux_share_a_kernel_with_different_lds_needs(nat, ctx):
     """The >48 KB dynamic-LDS permission belongs to the kernel function, not to a tableau: A (65.6 KB of LDS in
     stream_kernel<1024,4>), then B (49.7 KB, same function), then A again -- the second tableau must not lower what the

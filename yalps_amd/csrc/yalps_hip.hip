@@ -122,6 +122,10 @@ int fail(int code, const std::string &msg) {
 // not to a launch: raised once to the most a workgroup can have (one workgroup per CU; every kernel's static part is
 // below 2 KB), never to the size one tableau happens to need -- a second tableau with a smaller need would lower it
 // under the first one's feet.
+std::mutex &persistent_mutex(int device) {
+    static std::mutex mu[64];
+    return mu[device & 63];
+}
 constexpr size_t LDS_DYNAMIC_MAX = 160 * 1024 - 2048;
 int allow_big_lds(int device, const void *fn) {
     static std::mutex mu;
@@ -1013,13 +1017,19 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
                 HIP_TRY(hipMemcpyAsync(d.rhs[t->cur ^ 1], d.rhs[t->cur], sizeof(double) * (size_t)t->height,
                                        hipMemcpyDeviceToDevice, s));
             }
-            pv.fn<<<dim3(t->nb), dim3(pv.T), shmem, s>>>(t->d, parity, chunk);
-            t->last_path |= in_place ? 8 : 1;
-            t->last_launches++;
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(herr, t->d.rc_err, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipMemcpyAsync(&t->host_state[1], t->d.st + (parity ^ 1), sizeof(YState), hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
+            {
+                // A persistent kernel needs every workgroup of ITS grid on the chip.  Two of them from two contexts
+                // (threads) could each get half of the CUs and wait for the rest until their bounded spins give up:
+                // within this process, one at a time per device, from the launch to its completion.
+                std::lock_guard<std::mutex> one_grid(persistent_mutex(c->device));
+                pv.fn<<<dim3(t->nb), dim3(pv.T), shmem, s>>>(t->d, parity, chunk);
+                t->last_path |= in_place ? 8 : 1;
+                t->last_launches++;
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipMemcpyAsync(herr, t->d.rc_err, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipMemcpyAsync(&t->host_state[1], t->d.st + (parity ^ 1), sizeof(YState), hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+            }
             if (std::getenv("YALPS_HIP_DEBUG")) {
                 const YState &hs = t->host_state[1];
                 std::fprintf(stderr, "yalps_hip: persistent launch %lld err=%d status=%d phase=%d iter=%g pivots=%lld result=%g mbuf=%d chunk=%d\n",
