@@ -505,6 +505,37 @@ def test_inplace_path_sparse_netlib_whole_solve(nat, ctx, oracle):
     assert np.array_equal(got.view(np.int64), ref.view(np.int64))
 
 
+@pytest.mark.parametrize("M,N,check", [(300, 200, False), (1000, 500, False), (477, 54, True), (64, 512, False)])
+def test_resident_tagged_rows_equal_the_flag_protocol(nat, ctx, oracle, monkeypatch, M, N, check):
+    """resident_kernel<256,1,4,tag> (candidate rows as self-validating granules, the default for these shapes) against the
+    oracle and against the same variant with the drain + flag hand-off (YALPS_HIP_TAG=0): whole solves with a long phase 1."""
+    monkeypatch.setenv("YALPS_HIP_SMALL", "0")
+    w, h = N + 1, M + 1
+    m = nat.dense_lp(M, N, 9)
+    mm = m.reshape(h, w)
+    mm[1::3, 0] *= -0.05
+    mm[1::3, 1:] *= -1.0
+    mm[2::5, 2::3] = 0.0
+    pos = np.arange(w + h, dtype=np.int32)
+    ref, rp, rv = m.copy(), pos.copy(), pos.copy()
+    est, eres, epiv, _ = oracle.simplex(ref, w, h, rp, rv, max_pivots=5000, check_cycles=check)
+    for tag, name in (("1", "resident_kernel<256,1,4,tag>"), ("0", "resident_kernel<256,1,4>")):
+        monkeypatch.setenv("YALPS_HIP_TAG", tag)
+        c = nat.Context(0)
+        t = nat.DeviceTableau(c, w, h)
+        try:
+            t.upload(m, h, pos, pos.copy())
+            st, res, piv, _ = t.solve(max_pivots=5000, check_cycles=check)
+            info = t.info()
+            gm, gp, gv = t.download()
+        finally:
+            t.close()
+            c.close()
+        assert info["last_path"] == "resident" and info["resident"] == name, info
+        assert (st, piv) == (est, epiv) and G.same_number(res, eres)
+        assert np.array_equal(gm.view(np.int64), ref.view(np.int64)) and np.array_equal(gp, rp) and np.array_equal(gv, rv)
+
+
 def test_two_contexts_solve_concurrently_from_two_threads(nat, oracle):
     """Two contexts on one device, one thread each (ctypes releases the GIL during a solve): whole-chip persistent
     launches take turns inside the library, nobody falls off the resident path, both get the oracle's answer."""

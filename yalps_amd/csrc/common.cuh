@@ -71,6 +71,7 @@ struct Desc {
     // resident (on-chip) solver: per-workgroup candidate hand-off buffers, ping-pong by epoch parity
     double *rc_rows[2];             // [nb][pitch] candidate row of each workgroup
     double *rc_key[2];              // [nb] RHS entry of each workgroup's candidate row
+    double *rc_tag[2];              // [nb][2 * pitch + 2] the same as self-validating granules (resident_kernel<.., TAG>)
     unsigned long long *rc_flag[2]; // [nb][2] {candidate key bits, (epoch << 32) | global row index}
     int32_t *rc_err;                // set when a workgroup gives up waiting (never expected)
     unsigned long long *rc_verdict; // [2] checkCycles: workgroup 0's verdict on the pivot of an epoch, (epoch << 32) | cycled

@@ -19,6 +19,8 @@ PersistentTable yalps_resident_table_b();
 // resident_kernel<T, J, R, true>: up to XROWS more rows per workgroup parked in LDS
 PersistentTable yalps_resident_lds_table();
 constexpr int YALPS_RESIDENT_LDS_MAX_ROWS = 8;
+// resident_kernel<T, J, R, false, true>: the candidate row travels as self-validating granules (narrow rows)
+PersistentTable yalps_resident_tag_table();
 // stream_kernel<T, J, false> / <T, J, true> (with hasCycle): persistent, in place
 PersistentTable yalps_stream_table();
 PersistentTable yalps_stream_check_table();

@@ -50,7 +50,21 @@ __device__ __forceinline__ double2 ld16_sc1_one(const void *p) {
 }
 template <int J>
 __device__ __forceinline__ void ld16_sc1(double2 (&out)[J], const double *base, const int (&ofs)[J]) {
-    static_assert((J >= 1 && J <= 6) || J == 8, "lane units per row");
+    static_assert(J >= 1 && J <= 8, "lane units per row");
+    if constexpr (J == 7) { // (all seven in flight behind one wait)
+        v2f64 u[7];
+        asm volatile("global_load_dwordx4 %0, %7, off sc1\n\tglobal_load_dwordx4 %1, %8, off sc1\n\t"
+                     "global_load_dwordx4 %2, %9, off sc1\n\tglobal_load_dwordx4 %3, %10, off sc1\n\t"
+                     "global_load_dwordx4 %4, %11, off sc1\n\tglobal_load_dwordx4 %5, %12, off sc1\n\t"
+                     "global_load_dwordx4 %6, %13, off sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]), "=&v"(u[4]), "=&v"(u[5]), "=&v"(u[6])
+                     : "v"(base + ofs[0]), "v"(base + ofs[1]), "v"(base + ofs[2]), "v"(base + ofs[3]), "v"(base + ofs[4]),
+                       "v"(base + ofs[5]), "v"(base + ofs[6])
+                     : "memory");
+#pragma unroll
+        for (int j = 0; j < 7; j++) out[j] = make_double2(u[j].x, u[j].y);
+        return;
+    }
     if constexpr (J == 8) { // two groups of four
         double2 lo[4], hi[4];
         const int olo[4] = {ofs[0], ofs[1], ofs[2], ofs[3]}, ohi[4] = {ofs[4], ofs[5], ofs[6], ofs[7]};
@@ -106,8 +120,23 @@ __device__ __forceinline__ void ld16_sc1(double2 (&out)[J], const double *base, 
 // in LDS behind the basis, for tableaux a little beyond the register files: same arithmetic, same order of decisions,
 // the rows are read and written with 16-byte ds accesses at the columns the lane also holds of the register rows.
 constexpr int XROWS = 8; // most LDS rows per workgroup
-template <int T, int J, int R, bool X = false>
+// TAG = true (narrow rows, J <= 3): the candidate row travels as self-validating granules (Guideline 16 R2: "the data IS
+// the flag"): every double is ONE 16-byte sc1 store of two 8-byte granules {epoch, low word} {epoch, high word}.  The
+// publisher then neither drains nor joins a barrier before its key record leaves, and the readers of the winner's row
+// re-read its granules until every tag carries the epoch -- one fabric round trip less per pivot where the pivot is
+// all latency.  (The granule buffers are zeroed before every launch; epochs count from 1 within a launch.)
+__device__ __forceinline__ double2 tagged(unsigned epoch, double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v), t = (unsigned long long)epoch << 32;
+    return make_double2(__longlong_as_double((long long)(t | (u & 0xffffffffull))), __longlong_as_double((long long)(t | (u >> 32))));
+}
+__device__ __forceinline__ bool untag(unsigned epoch, double2 g, double &v) {
+    const unsigned long long lo = (unsigned long long)__double_as_longlong(g.x), hi = (unsigned long long)__double_as_longlong(g.y);
+    v = __longlong_as_double((long long)((lo & 0xffffffffull) | (hi << 32)));
+    return (unsigned)(lo >> 32) == epoch && (unsigned)(hi >> 32) == epoch;
+}
+template <int T, int J, int R, bool X = false, bool TAG = false>
 __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chunk) {
+    static_assert(!(X && TAG) && (!TAG || J <= 3), "tagged rows: narrow register-only variants");
     __shared__ double sk[2][16];
     __shared__ int si[2][16];
     __shared__ double sh_val[R + 2]; // per-row broadcast: pivot-column entry / entering-column entry
@@ -183,6 +212,7 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
 
     // ---- building blocks of one round ------------------------------------------------------------
     int la = 0; // entering column of the NEXT pivot (phase 2), priced on my objective replica
+    unsigned epoch = 0; // exchange round: publish() opens round epoch + 1 for the candidate candidate() has just left
     // Dantzig pricing (src/simplex.ts:71-79) on my replica of the objective row -> la
     auto price = [&]() __attribute__((always_inline)) {
         KI best = {INFINITY, INT_MAX};
@@ -230,15 +260,35 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
                 sh_ck = c.k;
                 sh_ci = c.i;
                 sh_cg = c.i == INT_MAX ? 0 : c.i / NB;
+                if constexpr (TAG) // the key record needs nothing else: it leaves before the candidate row is even finished
+                    st16_sc1(reinterpret_cast<double *>(d.rc_flag[(epoch + 1) & 1] + 2 * b),
+                             make_double2(c.k, __longlong_as_double((long long)(((unsigned long long)(epoch + 1) << 32) | (unsigned)c.i))));
             }
         }
         __syncthreads();
     };
-    unsigned epoch = 0;
     // publish my candidate (sh_ck / sh_ci) and the data of its row (register slot sh_cg)
     auto publish = [&]() __attribute__((always_inline)) {
         epoch++;
         const int par = epoch & 1, cg = sh_cg;
+        if constexpr (TAG) { // (the key record of this epoch left inside candidate())
+            double *dst = d.rc_tag[par] + (size_t)b * (2 * pitch + 2);
+#pragma unroll
+            for (int g = 0; g < R; g++) {
+                if (g == cg) {
+#pragma unroll
+                    for (int j = 0; j < J; j++) {
+                        const int c0 = 2 * (tid + j * T);
+                        if (c0 < pitch) {
+                            st16_sc1(dst + 2 * c0, tagged(epoch, x[g][j].x));
+                            st16_sc1(dst + 2 * c0 + 2, tagged(epoch, x[g][j].y));
+                        }
+                    }
+                }
+            }
+            if (tid == cg) st16_sc1(dst + 2 * pitch, tagged(epoch, my_rhs)); // the candidate row's RHS entry (lane cg)
+            return; // (no drain, no barrier, no flag: every granule says for itself which epoch it belongs to)
+        }
         // x[cg] straight from its registers: one uniform branch per slot, the slot index stays a
         // compile-time constant (a value select over the slots cost 4 R J v_cndmask and, with the copies
         // hipcc made for it, twice the registers; a runtime index would move the rows to scratch)
@@ -355,10 +405,40 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
         }
         const int row = c.i, owner = row % NB;
         // ---------------- the winner's raw row (sc1 loads only) ----------------------------------
-        const double *src = d.rc_rows[par] + (size_t)owner * pitch;
-        const double rhs_row = ld_sc1(d.rc_key[par] + owner);
+        double rhs_row;
         double2 pv[J];
-        ld16_sc1<J>(pv, src, cofs);
+        if constexpr (TAG) {
+            const double *src = d.rc_tag[par] + (size_t)owner * (2 * pitch + 2);
+            int gofs[2 * J + 1];
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                gofs[2 * j] = 2 * cofs[j];
+                gofs[2 * j + 1] = 2 * cofs[j] + 2;
+            }
+            gofs[2 * J] = 2 * pitch;
+            unsigned spins = 0;
+            for (;;) { // every wave for itself: re-read my granules until each carries this epoch
+                double2 g[2 * J + 1];
+                ld16_sc1<2 * J + 1>(g, src, gofs);
+                bool ok = untag(epoch, g[2 * J], rhs_row);
+#pragma unroll
+                for (int j = 0; j < J; j++) {
+                    ok &= untag(epoch, g[2 * j], pv[j].x);
+                    ok &= untag(epoch, g[2 * j + 1], pv[j].y);
+                }
+                if (__all(ok)) break;
+                if (++spins > (1u << 22) || __hip_atomic_load(d.rc_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    sh_fail = 1; // (acted upon behind the next barrier, where every wave sees it)
+                    __hip_atomic_store(d.rc_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        } else {
+            const double *src = d.rc_rows[par] + (size_t)owner * pitch;
+            rhs_row = ld_sc1(d.rc_key[par] + owner);
+            ld16_sc1<J>(pv, src, cofs);
+        }
         int col = la;
         if (phase == 1) { // :123-134
             KI e = {INFINITY, INT_MAX};
@@ -379,6 +459,7 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
             }
             e = block_argmin<T>(e, sk, si, slot);
             slot ^= 1;
+            if (TAG && sh_fail) return; // (the wait for the winner's granules gave up)
             if (e.i == INT_MAX) { // :135
                 term = YALPS_INFEASIBLE;
                 stop = true;
@@ -439,6 +520,7 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
         if constexpr (X)
             if (tid < E) sh_xcf[tid] = xl[tid * pitch + col - 1]; // (the rows are complete: every wave has passed the gather's barrier)
         __syncthreads();
+        if (TAG && sh_fail) return; // (the wait for the winner's granules gave up: uniform behind this barrier)
         const double q = sh_val[R + 1], coef0 = sh_val[R];
         double cf[R]; // uniform: pivot-column entry of each of my rows
 #pragma unroll

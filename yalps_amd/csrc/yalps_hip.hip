@@ -105,6 +105,8 @@ const std::vector<RVariant> kResident = variants_of({yalps_resident_table_a(), y
 // The same with up to XROWS more rows per workgroup parked in LDS (tableaux a little beyond the register files):
 // tried when no variant above fits; R = register rows, the LDS rows are what is missing.
 const std::vector<RVariant> kResidentLds = variants_of({yalps_resident_lds_table()});
+// resident_kernel<T, J, R, false, true>: the candidate row as self-validating granules (narrow rows; resident_kernel.cuh)
+const std::vector<RVariant> kResidentTag = variants_of({yalps_resident_tag_table()});
 constexpr int XROWS = YALPS_RESIDENT_LDS_MAX_ROWS;
 // stream_kernel<lanes, 16-byte units per lane and row, hasCycle>: same signature as the resident kernel
 const std::vector<RVariant> kStream = variants_of({yalps_stream_table()});
@@ -197,6 +199,9 @@ struct yalps_tableau {
     int64_t last_launches = 0;       // kernel launches of the last solve that did work (resident: chunks)
     size_t rshmem = 0;
     size_t rx_shmem = 0; // resident kernel with LDS rows: its (fixed) dynamic LDS size
+    RVariant rvar_tag{0, 0, 0, nullptr}; // the same variant with tagged candidate rows (fn == nullptr: not for this shape)
+    void *rc_tag_block = nullptr;        // its granule buffers, both parities: zeroed before every launch
+    size_t rc_tag_bytes = 0;
     int32_t *perm_backup = nullptr; // basis before the resident launch in flight (restored if it fails)
     int32_t perm_backup_len = 0;
     int32_t perm_len = 0; // entries of pos / var (width + GLOBAL height)
@@ -550,6 +555,17 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
         d.rc_flag[1] = base + nflag;
         d.rc_verdict = base + 2 * nflag;
         d.rc_err = reinterpret_cast<int32_t *>(base + 2 * nflag + 2);
+        // narrow rows: the tagged form of the same variant, if built (YALPS_HIP_TAG=0 switches it off)
+        if (t->rvar.fn && !d.extra && env_int("YALPS_HIP_TAG", 1))
+            for (const RVariant &v : kResidentTag)
+                if (v.T == t->rvar.T && v.J == t->rvar.J && v.R == t->rvar.R) t->rvar_tag = v;
+        if (t->rvar_tag.fn) {
+            const size_t row = 2 * (size_t)d.pitch + 2;
+            t->rc_tag_bytes = sizeof(double) * 2 * (size_t)t->nb * row;
+            HIP_TRY(hipMalloc(&t->rc_tag_block, t->rc_tag_bytes));
+            d.rc_tag[0] = static_cast<double *>(t->rc_tag_block);
+            d.rc_tag[1] = d.rc_tag[0] + (size_t)t->nb * row;
+        }
     }
     HIP_TRY(hipHostMalloc(&t->host_state, sizeof(YState) * 4 + sizeof(YConst), hipHostMallocDefault)); // 4 slots + YConst
     for (int k = 0; k < 4; k++) HIP_TRY(hipEventCreateWithFlags(&t->slot_ev[k], hipEventDisableTiming));
@@ -580,7 +596,7 @@ void yalps_tableau_destroy(yalps_tableau *t) {
         if (t->graph[k]) (void)hipGraphDestroy(t->graph[k]);
     }
     Desc &d = t->d;
-    void *bufs[] = {d.mat[0], d.mat[1], d.rhs[0], d.rhs[1], d.pos, d.var, d.st, d.cst, d.rc_rows[0], d.rc_rows[1], t->perm_backup,
+    void *bufs[] = {d.mat[0], d.mat[1], d.rhs[0], d.rhs[1], d.pos, d.var, d.st, d.cst, d.rc_rows[0], d.rc_rows[1], t->perm_backup, t->rc_tag_block,
                     d.rc_key[0], d.rc_key[1], t->rc_sync, d.gen_prow, d.gen_scal, d.part_ratio[0], d.part_ratio[1], d.part_rhs[0], d.part_rhs[1],
                     t->hist[0], t->hist[1], t->cells};
     for (void *p : bufs)
@@ -599,7 +615,7 @@ int32_t yalps_tableau_info(const yalps_tableau *t, char *buf, int32_t len) {
     char res[96] = "none", inp[64] = "none";
     if (t->rvar.fn)
         std::snprintf(res, sizeof res, "resident_kernel<%d,%d,%d%s> chunk=%d lds_rows=%d", t->rvar.T, t->rvar.J, t->rvar.R,
-                      t->d.extra ? ",lds" : "", RESIDENT_CHUNK, t->d.extra);
+                      t->d.extra ? ",lds" : t->rvar_tag.fn ? ",tag" : "", RESIDENT_CHUNK, t->d.extra);
     if (t->svar.fn) std::snprintf(inp, sizeof inp, "stream_kernel<%d,%d>", t->svar.T, t->svar.J);
     char str[64];
     if (t->wfn)
@@ -968,7 +984,7 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
         const bool use_stream = persistent_ok && !use_resident && c->inplace && (checkCycles ? t->svar_check.fn : t->svar.fn);
         if (!use_resident && !use_stream) break;
         const bool in_place = use_stream;
-        const RVariant &pv = in_place ? (checkCycles ? t->svar_check : t->svar) : t->rvar;
+        const RVariant &pv = in_place ? (checkCycles ? t->svar_check : t->svar) : t->rvar_tag.fn ? t->rvar_tag : t->rvar;
         bool &sattr = checkCycles ? t->sattr_check : t->sattr;
         const size_t shmem = in_place ? t->sshmem : t->rx_shmem ? t->rx_shmem : sizeof(int32_t) * 2 * (size_t)t->perm_len;
         if (in_place ? !sattr : shmem != t->rshmem) {
@@ -988,6 +1004,7 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
         int32_t *herr = reinterpret_cast<int32_t *>(&t->host_state[3]); // pinned scratch
         for (;;) {
             HIP_TRY(hipMemsetAsync(t->rc_sync, 0, t->rc_sync_bytes, s));
+            if (!in_place && t->rvar_tag.fn) HIP_TRY(hipMemsetAsync(t->rc_tag_block, 0, t->rc_tag_bytes, s)); // (tags: epochs restart at 1)
             if (checkCycles) { // room for every pivot this launch can record (no pause inside a persistent launch)
                 const int64_t have = hist_have;
                 if (have + chunk > t->hist_cap) {
