@@ -200,10 +200,15 @@ struct yalps_tableau {
     size_t rshmem = 0;
     size_t rx_shmem = 0; // resident kernel with LDS rows: its (fixed) dynamic LDS size
     RVariant rvar_tag{0, 0, 0, nullptr}; // the same variant with tagged candidate rows (fn == nullptr: not for this shape)
-    void *rc_tag_block = nullptr;        // its granule buffers, both parities: zeroed before every launch
-    size_t rc_tag_bytes = 0;
+    // Control block, ONE device allocation: [flags of both parities | verdict words | granules of the tagged variant |
+    // error word (16 B)] [st0 | st1 | cst].  rc_sync / rc_sync_bytes = its first part, zeroed by one memset before every
+    // persistent launch; [error word .. st1] comes back in one copy after it; [st0 .. cst] goes up in one copy when a solve
+    // starts.  (A fixed ~50 us per device solve was 10 stream operations; this and the one-block basis make it 6.)
+    void *ctl_block = nullptr;
+    char *host_ctl = nullptr;    // pinned: [st0 | st1 | cst] to send, then [error word | st0 | st1] as received
+    int32_t *perm_block = nullptr; // pos[] and var[] in one allocation (pos at 0, var at perm_cap): one copy backs both up
+    int32_t perm_cap = 0;
     int32_t *perm_backup = nullptr; // basis before the resident launch in flight (restored if it fails)
-    int32_t perm_backup_len = 0;
     int32_t perm_len = 0; // entries of pos / var (width + GLOBAL height)
     Variant var{};
     KernelFn wfn = nullptr; // wide_kernel variant used for FUSED / APPLY / SHARD launches when the tableau is
@@ -300,7 +305,6 @@ int init_state(yalps_tableau *t, double precision, double maxPivots, int32_t che
     hc.hist_entering = t->hist[1];
     hc.precision = precision;
     hc.max_pivots = maxPivots;
-    HIP_TRY(hipMemcpyAsync(t->d.cst, &hc, sizeof(YConst), hipMemcpyHostToDevice, s));
     YState *hs = &t->host_state[0];
     std::memset(hs, 0, sizeof(YState));
     hs->status = RUNNING;
@@ -308,7 +312,16 @@ int init_state(yalps_tableau *t, double precision, double maxPivots, int32_t che
     hs->bootstrap = 1;
     hs->mbuf = t->cur;
     hs->result = NAN;
-    HIP_TRY(hipMemcpyAsync(t->d.st, hs, sizeof(YState), hipMemcpyHostToDevice, s));
+    if (t->ctl_block) { // [st0 | st1 | cst] are adjacent on the device: one copy (st1 starts out zeroed)
+        char *stage = t->host_ctl;
+        std::memcpy(stage, hs, sizeof(YState));
+        std::memset(stage + sizeof(YState), 0, sizeof(YState));
+        std::memcpy(stage + 2 * sizeof(YState), &hc, sizeof(YConst));
+        HIP_TRY(hipMemcpyAsync(t->d.st, stage, 2 * sizeof(YState) + sizeof(YConst), hipMemcpyHostToDevice, s));
+    } else {
+        HIP_TRY(hipMemcpyAsync(t->d.cst, &hc, sizeof(YConst), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(t->d.st, hs, sizeof(YState), hipMemcpyHostToDevice, s));
+    }
     // (callers that go on to touch slot 0 from the host, or to copy on another stream, wait here; the solve
     // driver does not: everything it enqueues is ordered behind these two copies on the same stream)
     if (wait) HIP_TRY(hipStreamSynchronize(s));
@@ -488,11 +501,10 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
         HIP_TRY(hipMalloc(&d.gen_prow, sizeof(double) * (size_t)d.pitch));
         HIP_TRY(hipMalloc(&d.gen_scal, sizeof(double) * 4));
     }
-    HIP_TRY(hipMalloc(&d.pos, sizeof(int32_t) * (size_t)(width + hcap)));
-    HIP_TRY(hipMalloc(&d.var, sizeof(int32_t) * (size_t)(width + hcap)));
-    HIP_TRY(hipMalloc(&d.st, sizeof(YState) * 2));
-    HIP_TRY(hipMemsetAsync(d.st, 0, sizeof(YState) * 2, s));
-    HIP_TRY(hipMalloc(&d.cst, sizeof(YConst)));
+    t->perm_cap = (width + hcap + 3) / 4 * 4;
+    HIP_TRY(hipMalloc(&t->perm_block, sizeof(int32_t) * 2 * (size_t)t->perm_cap));
+    d.pos = t->perm_block;
+    d.var = t->perm_block + t->perm_cap;
     for (int k = 0; k < 2; k++) {
         HIP_TRY(hipMalloc(&d.part_ratio[k], sizeof(Part) * MAX_BLOCKS));
         HIP_TRY(hipMalloc(&d.part_rhs[k], sizeof(Part) * MAX_BLOCKS));
@@ -546,26 +558,34 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
             HIP_TRY(hipMalloc(&d.rc_rows[k], sizeof(double) * (size_t)t->nb * d.pitch));
             HIP_TRY(hipMalloc(&d.rc_key[k], sizeof(double) * ((size_t)t->nb + 8)));
         }
-        // flags of both parities, verdict words and the error word in ONE block: one memset per launch
-        const size_t nflag = 2 * (size_t)t->nb;
-        t->rc_sync_bytes = sizeof(unsigned long long) * (2 * nflag + 2) + 16;
-        HIP_TRY(hipMalloc(&t->rc_sync, t->rc_sync_bytes));
-        unsigned long long *base = static_cast<unsigned long long *>(t->rc_sync);
-        d.rc_flag[0] = base;
-        d.rc_flag[1] = base + nflag;
-        d.rc_verdict = base + 2 * nflag;
-        d.rc_err = reinterpret_cast<int32_t *>(base + 2 * nflag + 2);
+    }
+    {
+        static_assert(sizeof(YState) % 8 == 0 && sizeof(YConst) % 8 == 0, "control block layout");
+        const bool persistent = t->rvar.fn || t->svar.fn;
+        const size_t nflag = persistent ? 2 * (size_t)t->nb : 0;
         // narrow rows: the tagged form of the same variant, if built (YALPS_HIP_TAG=0 switches it off)
         if (t->rvar.fn && !d.extra && env_int("YALPS_HIP_TAG", 1))
             for (const RVariant &v : kResidentTag)
                 if (v.T == t->rvar.T && v.J == t->rvar.J && v.R == t->rvar.R) t->rvar_tag = v;
+        const size_t tag_row = 2 * (size_t)d.pitch + 2;
+        const size_t tag_bytes = t->rvar_tag.fn ? sizeof(double) * 2 * (size_t)t->nb * tag_row : 0;
+        t->rc_sync_bytes = sizeof(unsigned long long) * (2 * nflag + 2) + tag_bytes + 16; // (a multiple of 16)
+        HIP_TRY(hipMalloc(&t->ctl_block, t->rc_sync_bytes + 2 * sizeof(YState) + sizeof(YConst)));
+        HIP_TRY(hipMemsetAsync(t->ctl_block, 0, t->rc_sync_bytes + 2 * sizeof(YState) + sizeof(YConst), s));
+        t->rc_sync = t->ctl_block;
+        unsigned long long *base = static_cast<unsigned long long *>(t->ctl_block);
+        d.rc_flag[0] = base;
+        d.rc_flag[1] = base + nflag;
+        d.rc_verdict = base + 2 * nflag;
         if (t->rvar_tag.fn) {
-            const size_t row = 2 * (size_t)d.pitch + 2;
-            t->rc_tag_bytes = sizeof(double) * 2 * (size_t)t->nb * row;
-            HIP_TRY(hipMalloc(&t->rc_tag_block, t->rc_tag_bytes));
-            d.rc_tag[0] = static_cast<double *>(t->rc_tag_block);
-            d.rc_tag[1] = d.rc_tag[0] + (size_t)t->nb * row;
+            d.rc_tag[0] = reinterpret_cast<double *>(base + 2 * nflag + 2);
+            d.rc_tag[1] = d.rc_tag[0] + (size_t)t->nb * tag_row;
         }
+        char *tail = static_cast<char *>(t->ctl_block) + t->rc_sync_bytes;
+        d.rc_err = reinterpret_cast<int32_t *>(tail - 16);
+        d.st = reinterpret_cast<YState *>(tail);
+        d.cst = reinterpret_cast<YConst *>(tail + 2 * sizeof(YState));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&t->host_ctl), 16 + 2 * sizeof(YState) + sizeof(YConst), hipHostMallocDefault));
     }
     HIP_TRY(hipHostMalloc(&t->host_state, sizeof(YState) * 4 + sizeof(YConst), hipHostMallocDefault)); // 4 slots + YConst
     for (int k = 0; k < 4; k++) HIP_TRY(hipEventCreateWithFlags(&t->slot_ev[k], hipEventDisableTiming));
@@ -596,12 +616,15 @@ void yalps_tableau_destroy(yalps_tableau *t) {
         if (t->graph[k]) (void)hipGraphDestroy(t->graph[k]);
     }
     Desc &d = t->d;
-    void *bufs[] = {d.mat[0], d.mat[1], d.rhs[0], d.rhs[1], d.pos, d.var, d.st, d.cst, d.rc_rows[0], d.rc_rows[1], t->perm_backup, t->rc_tag_block,
-                    d.rc_key[0], d.rc_key[1], t->rc_sync, d.gen_prow, d.gen_scal, d.part_ratio[0], d.part_ratio[1], d.part_rhs[0], d.part_rhs[1],
+    // (pos / var and st / cst / the hand-off words are parts of perm_block and ctl_block where those exist: ordinary tableaux)
+    void *bufs[] = {d.mat[0], d.mat[1], d.rhs[0], d.rhs[1], t->perm_block ? nullptr : d.pos, t->perm_block ? nullptr : d.var, t->perm_block,
+                    t->ctl_block ? nullptr : d.st, t->ctl_block ? nullptr : d.cst, t->ctl_block, d.rc_rows[0], d.rc_rows[1], t->perm_backup,
+                    d.rc_key[0], d.rc_key[1], d.gen_prow, d.gen_scal, d.part_ratio[0], d.part_ratio[1], d.part_rhs[0], d.part_rhs[1],
                     t->hist[0], t->hist[1], t->cells};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (t->host_state) (void)hipHostFree(t->host_state);
+    if (t->host_ctl) (void)hipHostFree(t->host_ctl);
     if (t->pin_out) (void)hipHostFree(t->pin_out);
     for (auto &e : t->slot_ev)
         if (e) (void)hipEventDestroy(e);
@@ -1003,8 +1026,7 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
         int parity = 0;
         int32_t *herr = reinterpret_cast<int32_t *>(&t->host_state[3]); // pinned scratch
         for (;;) {
-            HIP_TRY(hipMemsetAsync(t->rc_sync, 0, t->rc_sync_bytes, s));
-            if (!in_place && t->rvar_tag.fn) HIP_TRY(hipMemsetAsync(t->rc_tag_block, 0, t->rc_tag_bytes, s)); // (tags: epochs restart at 1)
+            HIP_TRY(hipMemsetAsync(t->rc_sync, 0, t->rc_sync_bytes, s)); // (flags, verdicts, tags -- epochs restart at 1 --, error word)
             if (checkCycles) { // room for every pivot this launch can record (no pause inside a persistent launch)
                 const int64_t have = hist_have;
                 if (have + chunk > t->hist_cap) {
@@ -1019,14 +1041,8 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
                 }
             }
             // the kernel rewrites the basis (and, in place, the tableau): keep the old ones until the launch is known good
-            if (t->perm_backup_len < 2 * t->perm_len) {
-                if (t->perm_backup) HIP_TRY(hipFree(t->perm_backup));
-                HIP_TRY(hipMalloc(&t->perm_backup, sizeof(int32_t) * 2 * (size_t)t->perm_len));
-                t->perm_backup_len = 2 * t->perm_len;
-            }
-            HIP_TRY(hipMemcpyAsync(t->perm_backup, t->d.var, sizeof(int32_t) * (size_t)t->perm_len, hipMemcpyDeviceToDevice, s));
-            HIP_TRY(hipMemcpyAsync(t->perm_backup + t->perm_len, t->d.pos, sizeof(int32_t) * (size_t)t->perm_len,
-                                   hipMemcpyDeviceToDevice, s));
+            if (!t->perm_backup) HIP_TRY(hipMalloc(&t->perm_backup, sizeof(int32_t) * 2 * (size_t)t->perm_cap));
+            HIP_TRY(hipMemcpyAsync(t->perm_backup, t->perm_block, sizeof(int32_t) * 2 * (size_t)t->perm_cap, hipMemcpyDeviceToDevice, s));
             if (in_place) {
                 const Desc &d = t->d;
                 HIP_TRY(hipMemcpyAsync(d.mat[t->cur ^ 1], d.mat[t->cur], sizeof(double) * (size_t)d.pitch * t->height,
@@ -1043,9 +1059,11 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
                 t->last_path |= in_place ? 8 : 1;
                 t->last_launches++;
                 HIP_TRY(hipGetLastError());
-                HIP_TRY(hipMemcpyAsync(herr, t->d.rc_err, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-                HIP_TRY(hipMemcpyAsync(&t->host_state[1], t->d.st + (parity ^ 1), sizeof(YState), hipMemcpyDeviceToHost, s));
+                // [error word | st0 | st1] are adjacent: one copy back
+                HIP_TRY(hipMemcpyAsync(t->host_ctl, t->d.rc_err, 16 + 2 * sizeof(YState), hipMemcpyDeviceToHost, s));
                 HIP_TRY(hipStreamSynchronize(s));
+                std::memcpy(herr, t->host_ctl, sizeof(int32_t));
+                std::memcpy(&t->host_state[1], t->host_ctl + 16 + (size_t)(parity ^ 1) * sizeof(YState), sizeof(YState));
             }
             if (std::getenv("YALPS_HIP_DEBUG")) {
                 const YState &hs = t->host_state[1];
@@ -1059,9 +1077,7 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
                     c->inplace = false;
                 else
                     c->resident = false;
-                HIP_TRY(hipMemcpyAsync(t->d.var, t->perm_backup, sizeof(int32_t) * (size_t)t->perm_len, hipMemcpyDeviceToDevice, s));
-                HIP_TRY(hipMemcpyAsync(t->d.pos, t->perm_backup + t->perm_len, sizeof(int32_t) * (size_t)t->perm_len,
-                                       hipMemcpyDeviceToDevice, s));
+                HIP_TRY(hipMemcpyAsync(t->perm_block, t->perm_backup, sizeof(int32_t) * 2 * (size_t)t->perm_cap, hipMemcpyDeviceToDevice, s));
                 YState last;
                 HIP_TRY(hipMemcpy(&last, t->d.st + parity, sizeof(YState), hipMemcpyDeviceToHost));
                 t->cur = in_place ? last.mbuf ^ 1 : last.mbuf;
@@ -1221,10 +1237,14 @@ int32_t yalps_tableau_set_shard(yalps_tableau *t, int32_t rank, int32_t nranks, 
     // the permutations are global (every rank replays the same basis swaps)
     const size_t n = (size_t)d.w + (size_t)global_height;
     HIP_TRY(hipStreamSynchronize(s));
-    HIP_TRY(hipFree(d.pos));
-    HIP_TRY(hipFree(d.var));
-    HIP_TRY(hipMalloc(&d.pos, sizeof(int32_t) * n));
-    HIP_TRY(hipMalloc(&d.var, sizeof(int32_t) * n));
+    HIP_TRY(hipFree(t->perm_block)); // (pos and var share one allocation)
+    t->perm_block = nullptr;
+    if (t->perm_backup) HIP_TRY(hipFree(t->perm_backup));
+    t->perm_backup = nullptr;
+    t->perm_cap = (int32_t)((n + 3) / 4 * 4);
+    HIP_TRY(hipMalloc(&t->perm_block, sizeof(int32_t) * 2 * (size_t)t->perm_cap));
+    d.pos = t->perm_block;
+    d.var = t->perm_block + t->perm_cap;
     HIP_TRY(hipMemcpyAsync(d.pos, pos, sizeof(int32_t) * n, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d.var, var, sizeof(int32_t) * n, hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));
