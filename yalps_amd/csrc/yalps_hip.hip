@@ -758,16 +758,25 @@ int32_t yalps_tableau_download_solution(yalps_tableau *t, double *col0, int32_t 
     hipStream_t s = t->ctx->stream;
     // through pinned staging: three truly asynchronous copies and one wait (copies into pageable memory block one by one)
     const size_t ncol = sizeof(double) * (size_t)t->height, nperm = sizeof(int32_t) * (size_t)t->perm_len;
-    if (ncol + 2 * nperm > t->pin_out_bytes) {
+    if (ncol + 2 * nperm + sizeof(int32_t) * (size_t)t->perm_cap > t->pin_out_bytes) {
         if (t->pin_out) HIP_TRY(hipHostFree(t->pin_out));
         t->pin_out = nullptr;
         t->pin_out_bytes = 0;
-        const size_t cap = sizeof(double) * (size_t)t->d.hcap + 2 * sizeof(int32_t) * ((size_t)t->perm_len + t->d.hcap) + 64;
+        const size_t cap = sizeof(double) * (size_t)t->d.hcap + 2 * sizeof(int32_t) * ((size_t)t->perm_len + t->d.hcap + t->perm_cap) + 64;
         HIP_TRY(hipHostMalloc(&t->pin_out, cap, hipHostMallocDefault));
         t->pin_out_bytes = cap;
     }
     char *stage = static_cast<char *>(t->pin_out);
     HIP_TRY(hipMemcpyAsync(stage, t->d.rhs[t->cur], ncol, hipMemcpyDeviceToHost, s));
+    if (t->perm_block) { // pos[] and var[] share one allocation (var at perm_cap): one copy for both
+        const size_t span = sizeof(int32_t) * (size_t)t->perm_cap + nperm;
+        HIP_TRY(hipMemcpyAsync(stage + ncol, t->perm_block, span, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        std::memcpy(col0, stage, ncol);
+        std::memcpy(pos, stage + ncol, nperm);
+        std::memcpy(var, stage + ncol + sizeof(int32_t) * (size_t)t->perm_cap, nperm);
+        return 0;
+    }
     HIP_TRY(hipMemcpyAsync(stage + ncol, t->d.pos, nperm, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(stage + ncol + nperm, t->d.var, nperm, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -799,8 +808,10 @@ int32_t yalps_tableau_copy(yalps_tableau *dst, const yalps_tableau *src) {
     return 0;
 }
 
-int32_t yalps_tableau_apply_cuts(yalps_tableau *dst, const yalps_tableau *root, int32_t ncuts, const int32_t *cut_sign,
-                                 const int32_t *cut_variable, const double *cut_value) {
+// (wait = false: the caller goes on to solve dst on the same stream and waits there; the cut arrays are staged by the
+// copy call itself -- they are pageable memory -- so nothing of the caller's is read after the return)
+static int32_t apply_cuts_impl(yalps_tableau *dst, const yalps_tableau *root, int32_t ncuts, const int32_t *cut_sign,
+                               const int32_t *cut_variable, const double *cut_value, bool wait) {
     if (!dst || !root || dst == root || ncuts < 0 || (ncuts > 0 && (!cut_sign || !cut_variable || !cut_value)))
         return fail(YALPS_E_ARG, "yalps_tableau_apply_cuts: bad argument");
     if (root->height < 1 || dst->d.w != root->d.w || dst->ctx != root->ctx || root->d.nshards > 1 || dst->d.nshards > 1 ||
@@ -818,14 +829,19 @@ int32_t yalps_tableau_apply_cuts(yalps_tableau *dst, const yalps_tableau *root, 
         HIP_TRY(hipMemcpyAsync(dst->d.rhs[0], root->d.rhs[root->cur], sizeof(double) * (size_t)root->height,
                                hipMemcpyDeviceToDevice, s));
         const size_t nperm = sizeof(int32_t) * (size_t)(root->d.w + root->height);
-        HIP_TRY(hipMemcpyAsync(dst->d.pos, root->d.pos, nperm, hipMemcpyDeviceToDevice, s));
-        HIP_TRY(hipMemcpyAsync(dst->d.var, root->d.var, nperm, hipMemcpyDeviceToDevice, s));
+        if (dst->perm_block && root->perm_block && dst->perm_cap == root->perm_cap) { // same layout: pos and var in one copy
+            HIP_TRY(hipMemcpyAsync(dst->perm_block, root->perm_block, sizeof(int32_t) * (size_t)root->perm_cap + nperm,
+                                   hipMemcpyDeviceToDevice, s));
+        } else {
+            HIP_TRY(hipMemcpyAsync(dst->d.pos, root->d.pos, nperm, hipMemcpyDeviceToDevice, s));
+            HIP_TRY(hipMemcpyAsync(dst->d.var, root->d.var, nperm, hipMemcpyDeviceToDevice, s));
+        }
         dst->height = root->height;
         dst->perm_len = root->perm_len;
         dst->d.perm_len = root->perm_len;
     }
     if (ncuts == 0) {
-        HIP_TRY(hipStreamSynchronize(s));
+        if (wait) HIP_TRY(hipStreamSynchronize(s));
         return 0;
     }
     if (ncuts > dst->cells_cap) {
@@ -848,11 +864,16 @@ int32_t yalps_tableau_apply_cuts(yalps_tableau *dst, const yalps_tableau *root, 
     apply_cuts_kernel<<<dim3(ncuts), dim3(256), 0, s>>>(dst->d, root->d.mat[root->cur], root->d.rhs[root->cur], root->d.pos, h0,
                                                         ncuts, dsign, dvar, dval);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(s));
+    if (wait) HIP_TRY(hipStreamSynchronize(s));
     dst->height = h0 + ncuts;
     dst->perm_len = dst->d.w + dst->height;
     dst->d.perm_len = dst->perm_len;
     return 0;
+}
+
+int32_t yalps_tableau_apply_cuts(yalps_tableau *dst, const yalps_tableau *root, int32_t ncuts, const int32_t *cut_sign,
+                                 const int32_t *cut_variable, const double *cut_value) {
+    return apply_cuts_impl(dst, root, ncuts, cut_sign, cut_variable, cut_value, true);
 }
 
 // Any-shape fallback (generic_kernels.cuh): batches of DECIDE + APPLY launch pairs, state read back once per batch.
@@ -1041,8 +1062,14 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
                 }
             }
             // the kernel rewrites the basis (and, in place, the tableau): keep the old ones until the launch is known good
-            if (!t->perm_backup) HIP_TRY(hipMalloc(&t->perm_backup, sizeof(int32_t) * 2 * (size_t)t->perm_cap));
-            HIP_TRY(hipMemcpyAsync(t->perm_backup, t->perm_block, sizeof(int32_t) * 2 * (size_t)t->perm_cap, hipMemcpyDeviceToDevice, s));
+            // The resident kernel writes pos / var only where workgroup 0 leaves cleanly, and once it has, every workgroup has
+            // everything it needs to finish (all keys of the last epoch are out): a launch that reports a failed hand-off
+            // has not touched them.  In place (and for the test hook that declares a good launch failed) keep a copy.
+            const bool backup = in_place || c->resident_fault > 0;
+            if (backup) {
+                if (!t->perm_backup) HIP_TRY(hipMalloc(&t->perm_backup, sizeof(int32_t) * 2 * (size_t)t->perm_cap));
+                HIP_TRY(hipMemcpyAsync(t->perm_backup, t->perm_block, sizeof(int32_t) * 2 * (size_t)t->perm_cap, hipMemcpyDeviceToDevice, s));
+            }
             if (in_place) {
                 const Desc &d = t->d;
                 HIP_TRY(hipMemcpyAsync(d.mat[t->cur ^ 1], d.mat[t->cur], sizeof(double) * (size_t)d.pitch * t->height,
@@ -1077,7 +1104,8 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
                     c->inplace = false;
                 else
                     c->resident = false;
-                HIP_TRY(hipMemcpyAsync(t->perm_block, t->perm_backup, sizeof(int32_t) * 2 * (size_t)t->perm_cap, hipMemcpyDeviceToDevice, s));
+                if (backup)
+                    HIP_TRY(hipMemcpyAsync(t->perm_block, t->perm_backup, sizeof(int32_t) * 2 * (size_t)t->perm_cap, hipMemcpyDeviceToDevice, s));
                 YState last;
                 HIP_TRY(hipMemcpy(&last, t->d.st + parity, sizeof(YState), hipMemcpyDeviceToHost));
                 t->cur = in_place ? last.mbuf ^ 1 : last.mbuf;
