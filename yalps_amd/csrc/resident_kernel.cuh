@@ -1,5 +1,6 @@
 // resident_kernel.cuh -- persistent kernel, tableau resident in the register files
-// Part of libyalps_hip.so; included by yalps_hip.hip inside its anonymous namespace (gfx950 only).
+// Part of libyalps_hip.so; included by the persistent_resident_*.hip translation units inside their unnamed namespaces
+// (gfx950 only); its sc1 load / store helpers also serve stream_kernel.cuh.
 #pragma once
 
 // ------------------------------------------------------------------------------------------
@@ -21,6 +22,8 @@
 // timing: every decision is a deterministic function of bytes that are identical for all readers.
 // Every spin is bounded; a give-up sets rc_err and the host re-runs the chunk with the streaming
 // kernel from the untouched input buffer.
+// Two variations, template flags: X parks a few more rows per workgroup in LDS (tableaux a little beyond the register
+// files); TAG sends the candidate row as self-validating granules (Guideline 16 R2) for narrow rows.
 //
 // The kernel runs at most `chunk` pivots per launch (bounded run time; the host relaunches while
 // the status is RUNNING) and writes the tableau to the OTHER buffer on exit.

@@ -1,5 +1,5 @@
 // stream_kernel.cuh -- persistent IN-PLACE pivot loop for tableaux that do not fit on chip
-// Part of libyalps_hip.so; included by yalps_hip.hip inside its anonymous namespace (gfx950 only).
+// Part of libyalps_hip.so; included by persistent_stream.hip inside its unnamed namespace (gfx950 only).
 #pragma once
 
 // ------------------------------------------------------------------------------------------

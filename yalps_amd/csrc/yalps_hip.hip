@@ -5,13 +5,13 @@
 // code lives in the .cuh files included below:
 //   common.cuh           state / descriptors, DPP (key,index) arg-min reductions, small helpers
 //   resident_kernel.cuh  the fast tier: persistent kernel, tableau resident in the register files,
-//                        one L2 exchange (candidates + candidate rows) per pivot
+//                        one L2 exchange (candidates + candidate rows) per pivot   [compiled in persistent_resident_*.hip]
 //   pivot_kernel.cuh     streaming, one launch per pivot, rows batched in registers, tableau
 //                        ping-ponged in HBM; also DECIDE/APPLY for checkCycles
 //   wide_kernel.cuh      streaming for tableaux too wide / tall for register batches (pivot row in LDS)
 //   shard_kernels.cuh    row-sharded solve across GPUs: per-rank select kernel (+ MODE_SHARD above)
 //   assemble_kernels.cuh initial tableau from its written cells; applyCuts (branch-and-cut nodes) in HBM
-//   stream_kernel.cuh    persistent in-place pivot loop for tableaux beyond the on-chip size
+//   stream_kernel.cuh    persistent in-place pivot loop for tableaux beyond the on-chip size   [compiled in persistent_stream.hip]
 //   generic_kernels.cuh  any-shape fallback (rows wider than 16385 columns): DECIDE + APPLY launch per pivot
 //   wg_simplex.cuh       the whole simplex loop by one workgroup; small_kernel (tableau in LDS)
 //   batch_kernel.cuh     batched branch-and-cut nodes, one workgroup per node
