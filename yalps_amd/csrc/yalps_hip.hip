@@ -225,6 +225,12 @@ struct yalps_tableau {
     std::vector<char> cut_stage; // host side of yalps_tableau_apply_cuts' one packed upload
     void *pin_out = nullptr;     // pinned staging of yalps_tableau_download_solution
     size_t pin_out_bytes = 0;
+    // Internal callers that will want column 0 and the permutations right after the solve (branch-and-cut nodes) ask for
+    // them here: the persistent path then enqueues those copies behind every launch, in front of its one wait, and fills
+    // the arrays when that launch turns out to be the last (fetch_done) -- no second round trip for the download.
+    double *fetch_col0 = nullptr;
+    int32_t *fetch_pos = nullptr, *fetch_var = nullptr;
+    bool fetch_done = false;
     int64_t cells_cap = 0;
 };
 
@@ -752,11 +758,8 @@ int32_t yalps_tableau_assemble(yalps_tableau *t, int32_t height, int64_t nnz, co
     return 0;
 }
 
-int32_t yalps_tableau_download_solution(yalps_tableau *t, double *col0, int32_t *pos, int32_t *var) {
-    if (!t || !col0 || !pos || !var) return fail(YALPS_E_ARG, "yalps_tableau_download_solution: NULL argument");
-    HIP_TRY(hipSetDevice(t->ctx->device));
-    hipStream_t s = t->ctx->stream;
-    // through pinned staging: three truly asynchronous copies and one wait (copies into pageable memory block one by one)
+// pinned staging for column 0 + both permutations of the current height
+static int ensure_pin_out(yalps_tableau *t) {
     const size_t ncol = sizeof(double) * (size_t)t->height, nperm = sizeof(int32_t) * (size_t)t->perm_len;
     if (ncol + 2 * nperm + sizeof(int32_t) * (size_t)t->perm_cap > t->pin_out_bytes) {
         if (t->pin_out) HIP_TRY(hipHostFree(t->pin_out));
@@ -766,6 +769,16 @@ int32_t yalps_tableau_download_solution(yalps_tableau *t, double *col0, int32_t 
         HIP_TRY(hipHostMalloc(&t->pin_out, cap, hipHostMallocDefault));
         t->pin_out_bytes = cap;
     }
+    return 0;
+}
+
+int32_t yalps_tableau_download_solution(yalps_tableau *t, double *col0, int32_t *pos, int32_t *var) {
+    if (!t || !col0 || !pos || !var) return fail(YALPS_E_ARG, "yalps_tableau_download_solution: NULL argument");
+    HIP_TRY(hipSetDevice(t->ctx->device));
+    hipStream_t s = t->ctx->stream;
+    // through pinned staging: three truly asynchronous copies and one wait (copies into pageable memory block one by one)
+    const size_t ncol = sizeof(double) * (size_t)t->height, nperm = sizeof(int32_t) * (size_t)t->perm_len;
+    if (int rc = ensure_pin_out(t)) return rc;
     char *stage = static_cast<char *>(t->pin_out);
     HIP_TRY(hipMemcpyAsync(stage, t->d.rhs[t->cur], ncol, hipMemcpyDeviceToHost, s));
     if (t->perm_block) { // pos[] and var[] share one allocation (var at perm_cap): one copy for both
@@ -1088,7 +1101,23 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
                 HIP_TRY(hipGetLastError());
                 // [error word | st0 | st1] are adjacent: one copy back
                 HIP_TRY(hipMemcpyAsync(t->host_ctl, t->d.rc_err, 16 + 2 * sizeof(YState), hipMemcpyDeviceToHost, s));
+                const bool fetch = t->fetch_col0 && t->perm_block;
+                const size_t f_ncol = sizeof(double) * (size_t)t->height, f_nperm = sizeof(int32_t) * (size_t)t->perm_len;
+                if (fetch) { // (in case this launch is the last one: where it leaves column 0, and the basis)
+                    if (int rc2 = ensure_pin_out(t)) return rc2;
+                    char *stage = static_cast<char *>(t->pin_out);
+                    HIP_TRY(hipMemcpyAsync(stage, t->d.rhs[in_place ? t->cur : t->cur ^ 1], f_ncol, hipMemcpyDeviceToHost, s));
+                    HIP_TRY(hipMemcpyAsync(stage + f_ncol, t->perm_block, sizeof(int32_t) * (size_t)t->perm_cap + f_nperm, hipMemcpyDeviceToHost, s));
+                }
                 HIP_TRY(hipStreamSynchronize(s));
+                if (fetch && *reinterpret_cast<int32_t *>(t->host_ctl) == 0 && !(c->resident_fault > 0 && t->last_launches == c->resident_fault) &&
+                    reinterpret_cast<YState *>(t->host_ctl + 16)[parity ^ 1].status != RUNNING) {
+                    const char *stage = static_cast<const char *>(t->pin_out);
+                    std::memcpy(t->fetch_col0, stage, f_ncol);
+                    std::memcpy(t->fetch_pos, stage + f_ncol, f_nperm);
+                    std::memcpy(t->fetch_var, stage + f_ncol + sizeof(int32_t) * (size_t)t->perm_cap, f_nperm);
+                    t->fetch_done = true;
+                }
                 std::memcpy(herr, t->host_ctl, sizeof(int32_t));
                 std::memcpy(&t->host_state[1], t->host_ctl + 16 + (size_t)(parity ^ 1) * sizeof(YState), sizeof(YState));
             }
