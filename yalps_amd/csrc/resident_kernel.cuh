@@ -123,6 +123,9 @@ __device__ __forceinline__ void ld16_sc1(double2 (&out)[J], const double *base, 
 // in LDS behind the basis, for tableaux a little beyond the register files: same arithmetic, same order of decisions,
 // the rows are read and written with 16-byte ds accesses at the columns the lane also holds of the register rows.
 constexpr int XROWS = 8; // most LDS rows per workgroup
+#ifndef YALPS_SPLIT_NUM
+#define YALPS_SPLIT_NUM 1 // quarters of the register rows eliminated while the candidate row's stores drain
+#endif
 // TAG = true (narrow rows, J <= 3): the candidate row travels as self-validating granules (Guideline 16 R2: "the data IS
 // the flag"): every double is ONE 16-byte sc1 store of two 8-byte granules {epoch, low word} {epoch, high word}.  The
 // publisher then neither drains nor joins a barrier before its key record leaves, and the readers of the winner's row
@@ -140,6 +143,7 @@ __device__ __forceinline__ bool untag(unsigned epoch, double2 g, double &v) {
 template <int T, int J, int R, bool X = false, bool TAG = false>
 __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chunk) {
     static_assert(!(X && TAG) && (!TAG || J <= 3), "tagged rows: narrow register-only variants");
+    constexpr int SPLIT = TAG ? 0 : YALPS_SPLIT_NUM * R / 4; // other rows eliminated between the candidate row's stores and its flag
     __shared__ double sk[2][16];
     __shared__ int si[2][16];
     __shared__ double sh_val[R + 2]; // per-row broadcast: pivot-column entry / entering-column entry
@@ -270,8 +274,10 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
         }
         __syncthreads();
     };
-    // publish my candidate (sh_ck / sh_ci) and the data of its row (register slot sh_cg)
-    auto publish = [&]() __attribute__((always_inline)) {
+    // publish my candidate (sh_ck / sh_ci) and the data of its row (register slot sh_cg), in two steps: the stores, and --
+    // once they have drained -- the flag.  Between the two the caller eliminates SPLIT of its other rows: the drain is
+    // 1-2 us in which the workgroup would otherwise do nothing.
+    auto publish_stores = [&]() __attribute__((always_inline)) {
         epoch++;
         const int par = epoch & 1, cg = sh_cg;
         if constexpr (TAG) { // (the key record of this epoch left inside candidate())
@@ -317,11 +323,19 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
             }
         }
         if (tid == cg) st_sc1(d.rc_key[par] + b, my_rhs); // the candidate row's RHS entry (lane cg)
+    };
+    auto publish_flag = [&]() __attribute__((always_inline)) {
+        if constexpr (TAG) return;
+        const int par = epoch & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains ...
         __syncthreads();                                  // ... before ONE lane raises the flag:
         if (tid == 0) // ONE 16-byte record {candidate key, epoch << 32 | row}, one store, polled with one 16-byte load
             st16_sc1(reinterpret_cast<double *>(d.rc_flag[par] + 2 * b),
                      make_double2(sh_ck, __longlong_as_double((long long)(((unsigned long long)epoch << 32) | (unsigned)sh_ci))));
+    };
+    auto publish = [&]() __attribute__((always_inline)) {
+        publish_stores();
+        publish_flag();
     };
     // entries of my rows in column la, as the rows are now -> sh_val[0..R)
     auto column_la = [&]() __attribute__((always_inline)) {
@@ -578,9 +592,11 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
                 if (j == col_j) o[j] = with_elem(o[j], ecol, sh_nq[R]);
         }
         // my rows, fully, as pivot() leaves them: slot `only` (only_it = true) or all slots but it
-        auto finish_rows = [&](int only, bool only_it) __attribute__((always_inline)) {
+        // (register slots [glo, ghi); the rows parked in LDS go with the call that ends at R)
+        auto finish_rows = [&](int only, bool only_it, int glo, int ghi) __attribute__((always_inline)) {
 #pragma unroll
             for (int g = 0; g < R; g++) { // (g must stay a compile-time index: the rows are registers)
+            if (g < glo || g >= ghi) continue;
             if ((g == only) != only_it) continue;
             if (g == lslot) {
 #pragma unroll
@@ -600,7 +616,7 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
             }
             }
             if constexpr (X) {
-                for (int e = 0; e < E; e++) { // the parked rows: the same, through LDS
+                for (int e = 0; e < (ghi == R ? E : 0); e++) { // the parked rows: the same, through LDS
                     const int g = R + e;
                     if ((g == only) != only_it) continue;
                     double *xr = xl + e * pitch;
@@ -684,11 +700,13 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
             }
             candidate(phase);
             const int cg = sh_cg;
-            finish_rows(cg, true);
-            publish();
-            finish_rows(cg, false);
+            finish_rows(cg, true, 0, R);
+            publish_stores();
+            if constexpr (SPLIT > 0) finish_rows(cg, false, 0, SPLIT); // (while the stores drain)
+            publish_flag();
+            finish_rows(cg, false, SPLIT, R); // (while the flags travel)
         } else {
-            finish_rows(-1, false);
+            finish_rows(-1, false, 0, R);
         }
         if (b == 0 && tid == 0) { // basis bookkeeping, :7-12, in LDS (off the critical path)
             int *var = sh_perm, *pos = sh_perm + d.perm_len;
