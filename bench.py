@@ -39,6 +39,30 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+HBM_COPY_GBPS = 6290.0  # what a float4 copy reaches on this chip (same guide: 79 % of the spec peak)
+
+
+def onchip_floor_us(T, J, R, clock_ghz=2.4):
+    """What bounds resident_kernel<T,J,R> per pivot once the tableau sits in the register files: not HBM, but
+    (a) the one exchange through the fabric that every pivot needs, priced with the guide's own list
+        (MI355X_MICROARCH.md, "Persistent kernels: synchronisation and hand-off price list"):
+        handoff-flag, drained sc1 payload + 16-byte flag, idle chip .................. 1.3 us
+        handoff-payload, one dependent read of the winner's row (16-64 KB at the latency-bound
+        12-20 GB/s per block: row bytes / 16 GB/s, never under one Infinity-Cache round trip 0.23 us)
+    (b) the fp64 vector issue time of what cannot overlap the exchange: pivot-row normalisation, objective replica and
+        the candidate row (3 row passes of 2*J doubles per lane: mul + sub, 4 cycles per wave64 fp64 instruction,
+        T/256 waves per SIMD), and of the remaining R-1 rows where that exceeds the time the flags travel (0.5 us).
+    floor = (a) + (b); frac = floor / measured.  A model, stated so that it can be checked -- not a measurement."""
+    row_bytes = 16 * T * J
+    exchange = 1.3 + max(row_bytes / 16e3, 0.23)
+    waves_per_simd = T / 256.0
+    per_row = 2 * J * 2 * 4 * waves_per_simd / (clock_ghz * 1e3)  # us: 2J doubles x (mul + sub) x 4 cycles
+    critical = 3 * per_row
+    rest = max(0.0, (R - 1) * per_row - 0.5)
+    return {"us": exchange + critical + rest, "exchange_us": exchange, "valu_critical_us": critical, "valu_rest_us": rest,
+            "valu_all_rows_us": (R + 2) * per_row, "model": "handoff-flag 1.3 us + winner's row %d B / 16 GB/s + fp64 issue of 3 row "
+            "passes + what of the other %d rows exceeds 0.5 us of flag travel (4 cycles per wave64 fp64 op, %g waves/SIMD, %.1f GHz)"
+            % (row_bytes, R - 1, waves_per_simd, clock_ghz)}
 
 
 def algorithmic_bytes_per_pivot(h, w):
@@ -61,11 +85,13 @@ def measured_traffic(size, resident, pivots_per_launch):
     return rec["traffic_bytes_per_launch"]
 
 
-def cpu_baseline(M, N, seed, budget_pivots):
+def cpu_baseline(M, N, seed, budget_pivots, threads=1):
     """Oracle (kind "port") on a bounded sample: the first `budget_pivots` pivots of the same LP
-    (all of them by default: 3923 pivots of the 2049x2049 tableau take ~7-10 s on one core)."""
+    (all of them by default: 3923 pivots of the 2049x2049 tableau take ~7-10 s on one core).
+    threads > 1: the row-parallel build of the same source (liboracle_omp.so)."""
     from tests import _oracle
-    orc = _oracle.load()
+    orc = _oracle.load(omp=threads > 1)
+    cores = orc.set_threads(threads) if threads > 1 else 1
     w, h = N + 1, M + 1
     m = orc.dense_lp(M, N, seed)
     pos = np.arange(w + h, dtype=np.int32)
@@ -73,9 +99,10 @@ def cpu_baseline(M, N, seed, budget_pivots):
     t0 = time.perf_counter()
     _, _, npiv, _ = orc.simplex(m, w, h, pos, var, max_pivots=budget_pivots)
     dt = time.perf_counter() - t0
-    return {"value": npiv / dt, "unit": "pivots/s", "cores": 1, "kind": "port",
-            "sample": "%d pivots of dense-LP(%d,%d,seed=%d), oracle/simplex_oracle.c -O2 -ffp-contract=off, %.1f s, host has %d cores"
-                      % (npiv, M, N, seed, dt, os.cpu_count())}
+    return {"value": npiv / dt, "unit": "pivots/s", "cores": cores, "kind": "port",
+            "sample": "%d pivots of dense-LP(%d,%d,seed=%d), oracle/simplex_oracle.c -O2 -ffp-contract=off%s, %.1f s, host has %d cores"
+                      % (npiv, M, N, seed, " -fopenmp (row loop of the elimination over %d threads)" % cores if threads > 1 else "",
+                         dt, os.cpu_count())}
 
 
 def main():
@@ -86,6 +113,8 @@ def main():
     ap.add_argument("--size", type=int, default=2048, help="M = N of dense-LP(M,N,seed)")
     ap.add_argument("--cpu-pivots", type=float, default=float("inf"),
                     help="oracle sample: first N pivots of the same LP (default: the whole solve, ~7 s; 0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=16,
+                    help="threads of the second, row-parallel oracle run (a 1-GPU box's CPU share; 0 = skip)")
     ap.add_argument("--sweep-launches", type=int, default=400)
     ap.add_argument("--workload", choices=("replicas", "sharded"), default="replicas")
     ap.add_argument("--pivots-per-step", type=int, default=256, help="sharded workload: pivots per step")
@@ -186,17 +215,31 @@ def main():
             ach = bytes_launch / (us_launch * 1e-6) / 1e9
             out["roofline"] = {
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+                "frac_of_copy_rate": ach / HBM_COPY_GBPS,
                 "traffic": None if inplace else measured_traffic(args.size, resident, bytes_launch / bpp),
                 "kernel": info["resident"].split(" ")[0] if resident else info["inplace"] if inplace else info["streaming"],
                 "launches_per_step": launches, "avg_us": us_launch, "bytes_per_launch": bytes_launch,
                 "us_per_pivot": us_pivot,
-                "note": ("persistent kernel: one launch = up to %s pivots with the tableau resident in registers; "
-                         "algorithmic bytes (SURVEY 8d, 16*h*w per pivot) / HIP-event time. frac > 1 means faster "
-                         "than streaming the tableau through HBM could ever be; real HBM traffic is `traffic`."
+                "note": ("persistent kernel: one launch = up to %s pivots with the tableau resident in registers; achieved = "
+                         "algorithmic bytes (SURVEY 8d, 16*h*w per pivot) / HIP-event time, kept as algorithmic_equiv; real HBM "
+                         "traffic is `traffic`; frac = onchip_floor.us / us_per_pivot, the bound that binds this kernel."
                          % info.get("chunk", "?")) if resident else
                         ("persistent in-place kernel: one launch = many pivots, rows streamed from HBM / Infinity Cache; "
                          "algorithmic bytes (SURVEY 8d) / HIP-event time") if inplace else
                         "one launch = one pivot; HIP events over the timed pivot loops / pivots"}
+            if resident:
+                # HBM does not bind a kernel that keeps the tableau in registers (measured traffic: a few per cent of the
+                # algorithmic bytes): `frac` is the fraction of the bound that does bind it, the algorithmic figure stays
+                # beside it under its own name
+                T, J, R = (int(x) for x in info["resident"].split("<")[1].split(">")[0].split(",")[:3])
+                floor = onchip_floor_us(T, J, R)
+                rf = out["roofline"]
+                rf["algorithmic_equiv"] = {"achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+                                           "frac_of_copy_rate": ach / HBM_COPY_GBPS,
+                                           "note": "what a streaming implementation would have to move / time; not an efficiency"}
+                rf["onchip_floor"] = floor
+                rf["frac"] = floor["us"] / us_pivot
+                rf["bound_detail"] = "on-chip: exchange latency through the fabric + fp64 vector issue (see onchip_floor.model)"
             work.copy_from(pristine)
             us_apply = work.bench_sweep(h // 2, w // 2, args.sweep_launches)
             out["streaming_apply_only"] = {
@@ -204,6 +247,9 @@ def main():
                 "note": "the general (HBM-streaming) kernel in APPLY mode, fixed pivot, back-to-back launches"}
             if args.cpu_pivots > 0:
                 out["cpu_baseline"] = cpu_baseline(M, N, seed, args.cpu_pivots)
+                threads = min(args.cpu_threads, os.cpu_count() or 1)
+                if threads > 1:
+                    out["cpu_baseline_all_cores"] = cpu_baseline(M, N, seed, args.cpu_pivots, threads)
     work.close()
     pristine.close()
     ctx.close()

@@ -128,6 +128,11 @@ int32_t yalps_tableau_apply_cuts(yalps_tableau *dst, const yalps_tableau *root, 
 int32_t yalps_tableau_height(const yalps_tableau *t);
 /* Which kernels this tableau uses and which path the last solve took (text, for benchmarks). */
 int32_t yalps_tableau_info(const yalps_tableau *t, char *buf, int32_t len);
+/* Diagnostic build only (library compiled with -DYALPS_STAMPS; tools/resident_stages.py): per-workgroup sums of
+ * in-kernel stage stamps of the persistent launches since the last reset, 24 uint64 words per workgroup (stage sums in
+ * shader cycles [0..19], pivots [20], s_memtime span [21], s_memrealtime span [22]).  Returns the number of words
+ * copied; the shipped library executes no stamp and returns YALPS_E_ARG. */
+int32_t yalps_tableau_debug_stamps(yalps_tableau *t, uint64_t *out, int32_t cap_words, int32_t reset);
 
 /* Run the two-phase simplex on the resident tableau (in place).  gpu_ms_out (optional) =
  * HIP-event time of the whole pivot loop on the context's stream. */

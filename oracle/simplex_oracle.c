@@ -50,6 +50,20 @@ typedef struct {
     int64_t len, cap;
 } yo_hist;
 
+#ifdef _OPENMP
+#include <omp.h>
+/* threads of the row-parallel build (0 = leave OpenMP's default); returns the count in force */
+int32_t yalps_oracle_set_threads(int32_t n) {
+    if (n > 0) omp_set_num_threads(n);
+    return (int32_t)omp_get_max_threads();
+}
+#else
+int32_t yalps_oracle_set_threads(int32_t n) {
+    (void)n;
+    return 1;
+}
+#endif
+
 /* JS Math.round: nearest integer, halves toward +infinity (src/util.ts:2-3). */
 static double js_round(double x) {
     if (!(x == x) || isinf(x)) return x;
@@ -90,7 +104,12 @@ static void yo_pivot(yo_tab *t, int32_t row, int32_t col) {
     }
     prow[col] = 1.0 / quotient; /* :25 */
 
-    /* :27-38 eliminate the pivot column from every other row */
+    /* :27-38 eliminate the pivot column from every other row.  (liboracle_omp.so, -fopenmp: the rows are independent,
+     * so the row loop may be split over threads without changing one bit -- the all-core CPU baseline of BASELINE.md
+     * section 4.2; liboracle.so is built without OpenMP and ignores the pragma.) */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) if (h >= 64)
+#endif
     for (int32_t r = 0; r < h; r++) {
         if (r == row) continue;
         double *mr = m + (size_t)r * w;

@@ -26,6 +26,12 @@ class Oracle:
         lib.yalps_oracle_dense_lp_f64.argtypes = [C.c_int32, C.c_int32, C.c_double, _f64p]
         lib.yalps_oracle_round_to_precision.restype = C.c_double
         lib.yalps_oracle_round_to_precision.argtypes = [C.c_double, C.c_double]
+        lib.yalps_oracle_set_threads.restype = C.c_int32
+        lib.yalps_oracle_set_threads.argtypes = [C.c_int32]
+
+    def set_threads(self, n):
+        """Row-parallel build only (load(omp=True)); returns the thread count in force (1 for the scalar build)."""
+        return self.lib.yalps_oracle_set_threads(int(n))
 
     def simplex(self, matrix, width, height, pos, var, precision=1e-8, max_pivots=8192.0, check_cycles=False,
                 trace_cap=0):
@@ -53,14 +59,16 @@ class Oracle:
         return self.lib.yalps_oracle_round_to_precision(x, precision)
 
 
-def build():
-    subprocess.run(["make", "-s", "-C", ORACLE_DIR, "liboracle.so"], check=True)
-    return os.path.join(ORACLE_DIR, "liboracle.so")
+def build(name="liboracle.so"):
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR, name], check=True)
+    return os.path.join(ORACLE_DIR, name)
 
 
-def load():
-    path = os.path.join(ORACLE_DIR, "liboracle.so")
+def load(omp=False):
+    """omp=True: liboracle_omp.so, the same source with the elimination's row loop split over threads (-fopenmp)."""
+    name = "liboracle_omp.so" if omp else "liboracle.so"
+    path = os.path.join(ORACLE_DIR, name)
     src = os.path.join(ORACLE_DIR, "simplex_oracle.c")
     if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
-        build()
+        build(name)
     return Oracle(C.CDLL(path))

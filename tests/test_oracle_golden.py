@@ -38,6 +38,20 @@ def test_oracle_reproduces_reference_c2(oracle, rec):
     assert rec["n_pivots"] == 3923 and rec["result"] == -1022.09813705
 
 
+OMP_RECORDS = [pytest.param(r, id=G.label(r)) for r in G.records("dense") if 64 <= r["M"] <= 512] + \
+              [pytest.param(r, id=G.label(r)) for r in G.records("cases") if r["height"] >= 64][:6]
+
+
+@pytest.mark.parametrize("rec", OMP_RECORDS)
+def test_row_parallel_oracle_reproduces_reference(rec):
+    """liboracle_omp.so (the same source with -fopenmp: the elimination's row loop over threads; the all-core CPU
+    baseline of bench.py) is pinned by the same golden records."""
+    from tests import _oracle
+    omp = _oracle.load(omp=True)
+    assert omp.set_threads(4) == 4
+    _check(omp, rec)
+
+
 def test_round_to_precision_js_semantics(oracle):
     # Math.round rounds halves toward +inf (src/util.ts:1-4)
     assert oracle.round_to_precision(-14666.666666666668, 1e-8) == -14666.66666667

@@ -23,6 +23,7 @@ SYMBOLS = (
     "yalps_round_to_precision", "yalps_ctx_create_on_stream", "yalps_tableau_set_shard", "yalps_shard_slot_doubles",
     "yalps_shard_begin", "yalps_shard_select", "yalps_shard_apply", "yalps_shard_poll", "yalps_tableau_info",
     "yalps_tableau_assemble", "yalps_simplex_sparse_f64", "yalps_tableau_apply_cuts", "yalps_tableau_download_solution", "yalps_milp_f64", "yalps_batch_create", "yalps_batch_destroy", "yalps_batch_set_root", "yalps_batch_solve", "yalps_batch_download",
+    "yalps_tableau_debug_stamps",
 )
 
 
@@ -106,6 +107,8 @@ def lib():
         L.yalps_tableau_height.argtypes = [vp]
         L.yalps_tableau_info.restype = C.c_int32
         L.yalps_tableau_info.argtypes = [vp, C.c_char_p, C.c_int32]
+        L.yalps_tableau_debug_stamps.restype = C.c_int32
+        L.yalps_tableau_debug_stamps.argtypes = [vp, vp, C.c_int32, C.c_int32]
         L.yalps_tableau_solve.restype = C.c_int32
         L.yalps_tableau_solve.argtypes = [vp, C.c_double, C.c_double, C.c_int32, f64p, C.POINTER(C.c_int64),
                                           C.POINTER(C.c_float)]
@@ -261,6 +264,12 @@ class DeviceTableau:
         buf = C.create_string_buffer(512)
         check(lib().yalps_tableau_info(self.handle, buf, 512))
         return dict(kv.split("=", 1) for kv in buf.value.decode().split(" ") if "=" in kv)
+
+    def debug_stamps(self, reset=True):
+        """Diagnostic build only: (workgroups, 24) uint64 stage sums of the persistent launches (yalps_tableau_debug_stamps)."""
+        out = np.zeros(1024 * 24, np.uint64)
+        n = check(lib().yalps_tableau_debug_stamps(self.handle, out.ctypes.data, out.size, int(bool(reset))))
+        return out[:n].reshape(-1, 24)
 
     def pivot(self, row, col):
         check(lib().yalps_tableau_pivot(self.handle, row, col))

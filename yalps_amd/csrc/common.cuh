@@ -80,7 +80,11 @@ struct Desc {
     int32_t xl_ofs; // ... and where they start in the dynamic LDS block, in int32 units (behind var[] / pos[] at capacity)
     // any-shape fallback (generic_kernels.cuh): the normalised pivot row [pitch] and {quotient, its RHS, RHS non-zero}
     double *gen_prow, *gen_scal;
+    // diagnostic build only (-DYALPS_STAMPS, never the shipped library): [nb][STAMP_WORDS] per-workgroup stage sums in
+    // shader cycles, written once when a persistent launch ends; no kernel reads it
+    unsigned long long *dbg;
 };
+constexpr int STAMP_WORDS = 24; // stage sums [0..19], pivots [20], s_memtime span [21], s_memrealtime span [22]
 
 // ------------------------------------------------------------------------------------------
 // 64-lane arg-min with lowest-index tie-break (all four scans of the reference reduce to it).
@@ -203,6 +207,18 @@ __device__ __forceinline__ bool has_cycle(const YConst *C, int64_t hist_len, int
     if (found) *flag = 1;
     __syncthreads();
     return *flag != 0;
+}
+
+// Bounded waits of the persistent kernels' hand-offs.  A poll loop calls this once per unsuccessful poll; every 64th call
+// reads the 100 MHz real-time counter and the launch's error word: true = give up (somebody else already has, or this
+// wait has lasted SPIN_GIVE_UP_TICKS: the grid is not co-resident -- a foreign kernel holds CUs -- or a workgroup died).
+// The caller then sets the error word and leaves; the host falls back to the launch-per-pivot kernels (yalps_hip.hip).
+constexpr unsigned long long SPIN_GIVE_UP_TICKS = 5000000ull; // 50 ms (a pivot's hand-off takes microseconds)
+__device__ __forceinline__ bool spin_expired(unsigned &spins, unsigned long long &t0, const int32_t *err_word) {
+    if ((++spins & 63u) != 0) return false;
+    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+    if (spins == 64u) t0 = now;
+    return now - t0 > SPIN_GIVE_UP_TICKS || __hip_atomic_load(err_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
 }
 
 // Sout = Sin, 16 bytes at a time, straight from global to global (a `YState s = *Sin` local copy

@@ -16,6 +16,9 @@ struct PersistentTable {
 // resident_kernel<T, J, R>: tableau in the register files
 PersistentTable yalps_resident_table_a();
 PersistentTable yalps_resident_table_b();
+// resident2_kernel<T, J, R>: the same shapes with the second-generation pivot loop (resident2_kernel.cuh)
+PersistentTable yalps_resident2_table_a();
+PersistentTable yalps_resident2_table_b();
 // resident_kernel<T, J, R, true>: up to XROWS more rows per workgroup parked in LDS
 PersistentTable yalps_resident_lds_table();
 constexpr int YALPS_RESIDENT_LDS_MAX_ROWS = 8;

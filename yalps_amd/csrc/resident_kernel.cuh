@@ -123,6 +123,22 @@ __device__ __forceinline__ void ld16_sc1(double2 (&out)[J], const double *base, 
 // in LDS behind the basis, for tableaux a little beyond the register files: same arithmetic, same order of decisions,
 // the rows are read and written with 16-byte ds accesses at the columns the lane also holds of the register rows.
 constexpr int XROWS = 8; // most LDS rows per workgroup
+// Stage stamps (CDNA guide 7, In-kernel stamps): only in the diagnostic build (-DYALPS_STAMPS -> libyalps_hip_stamps.so,
+// tools/resident_stages.py); the shipped kernels execute none.  Sums of s_memtime differences per stage, kept in
+// scalar registers, stored once by lane 0 when the launch ends, to a buffer nothing else reads.
+#ifdef YALPS_STAMPS
+#define YSTAMP(k)                                                                                           \
+    do {                                                                                                    \
+        unsigned long long t_;                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        st_acc[k] += t_ - st_last;                                                                          \
+        st_last = t_;                                                                                       \
+    } while (0)
+#else
+#define YSTAMP(k) do { } while (0)
+#endif
 #ifndef YALPS_SPLIT_NUM
 #define YALPS_SPLIT_NUM 1 // quarters of the register rows eliminated while the candidate row's stores drain
 #endif
@@ -354,6 +370,9 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
     int done = 0, term = RUNNING;
     double term_result = NAN;
     bool stop = false;
+#ifdef YALPS_STAMPS
+    unsigned long long st_acc[20] = {}, st_last = 0, st_t0 = 0, st_r0 = 0;
+#endif
     // loop bound, optimality: checked before every exchange (src/simplex.ts:69,109 and :80)
     auto check = [&]() __attribute__((always_inline)) {
         if (done == chunk) {
@@ -375,6 +394,10 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
         candidate(phase);
         publish();
     }
+#ifdef YALPS_STAMPS
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t0), "=s"(st_r0)::"memory");
+    st_last = st_t0;
+#endif
     // (single back edge, single exit: every `stop` is a flag, so the rows stay in one set of registers)
     while (!stop) {
         // ---------------- gather everyone's candidate -------------------------------------------
@@ -384,12 +407,13 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
             // key and tag are one 16-byte record, written by one store and read by one load
             unsigned long long f = 0;
             unsigned spins = 0;
+            unsigned long long spin_t0 = 0;
             double2 rec;
             for (;;) {
                 rec = ld16_sc1_one(d.rc_flag[par] + 2 * tid);
                 f = (unsigned long long)__double_as_longlong(rec.y);
                 if ((unsigned)(f >> 32) == epoch) break;
-                if (++spins > (1u << 22) || __hip_atomic_load(d.rc_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                if (spin_expired(spins, spin_t0, d.rc_err)) {
                     sh_fail = 1;
                     __hip_atomic_store(d.rc_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
@@ -399,8 +423,10 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
             c.i = (int)(unsigned)f;
             c.k = rec.x;
         }
+        YSTAMP(0); // wait for everybody's flag (waves 0 .. NB/64 - 1; the others go straight to the barrier)
         c = block_argmin<T>(c, sk, si, slot); // (its barrier is the one the polling waves join)
         slot ^= 1;
+        YSTAMP(1);
         if (sh_fail) return; // uniform: written before the barrier above
         if (c.i == INT_MAX) {
             if (phase == 1) { // :120 phase 1 is over: same tableau, now the min-ratio exchange
@@ -418,6 +444,7 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
                 term_result = (double)la;
                 stop = true;
             }
+            YSTAMP(14);
             continue;
         }
         const int row = c.i, owner = row % NB;
@@ -434,6 +461,7 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
             }
             gofs[2 * J] = 2 * pitch;
             unsigned spins = 0;
+            unsigned long long spin_t0 = 0;
             for (;;) { // every wave for itself: re-read my granules until each carries this epoch
                 double2 g[2 * J + 1];
                 ld16_sc1<2 * J + 1>(g, src, gofs);
@@ -444,7 +472,7 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
                     ok &= untag(epoch, g[2 * j + 1], pv[j].y);
                 }
                 if (__all(ok)) break;
-                if (++spins > (1u << 22) || __hip_atomic_load(d.rc_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                if (spin_expired(spins, spin_t0, d.rc_err)) {
                     sh_fail = 1; // (acted upon behind the next barrier, where every wave sees it)
                     __hip_atomic_store(d.rc_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
@@ -456,6 +484,7 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
             rhs_row = ld_sc1(d.rc_key[par] + owner);
             ld16_sc1<J>(pv, src, cofs);
         }
+        YSTAMP(2); // the winner's row
         int col = la;
         if (phase == 1) { // :123-134
             KI e = {INFINITY, INT_MAX};
@@ -496,10 +525,11 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
                 if (tid == 0) {
                     unsigned long long v = 0;
                     unsigned spins = 0;
+            unsigned long long spin_t0 = 0;
                     for (;;) {
                         v = __hip_atomic_load(d.rc_verdict + par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if ((unsigned)(v >> 32) == epoch) break;
-                        if (++spins > (1u << 22) || __hip_atomic_load(d.rc_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        if (spin_expired(spins, spin_t0, d.rc_err)) {
                             sh_fail = 1;
                             __hip_atomic_store(d.rc_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             break;
@@ -519,6 +549,7 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
                 continue;
             }
         }
+        YSTAMP(3); // phase 1: entering column; checkCycles: verdict
         // ---------------- pivot (src/simplex.ts:5-39) on my registers ----------------------------
         // Order: everything the NEXT exchange needs first (objective replica -> la, my rows' entries
         // of column la and RHS -> my candidate, that one row), publish, and only then the other rows:
@@ -537,6 +568,7 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
         if constexpr (X)
             if (tid < E) sh_xcf[tid] = xl[tid * pitch + col - 1]; // (the rows are complete: every wave has passed the gather's barrier)
         __syncthreads();
+        YSTAMP(4); // pivot column of my rows through LDS
         if (TAG && sh_fail) return; // (the wait for the winner's granules gave up: uniform behind this barrier)
         const double q = sh_val[R + 1], coef0 = sh_val[R];
         double cf[R]; // uniform: pivot-column entry of each of my rows
@@ -591,6 +623,7 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
             for (int j = 0; j < J; j++)
                 if (j == col_j) o[j] = with_elem(o[j], ecol, sh_nq[R]);
         }
+        YSTAMP(5); // normalise, column divisions, RHS, objective replica
         // my rows, fully, as pivot() leaves them: slot `only` (only_it = true) or all slots but it
         // (register slots [glo, ghi); the rows parked in LDS go with the call that ends at R)
         auto finish_rows = [&](int only, bool only_it, int glo, int ghi) __attribute__((always_inline)) {
@@ -652,6 +685,7 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
         done += 1;
         price(); // la of the next pivot, from the updated objective replica
         check();
+        YSTAMP(6);
         if (!stop) {
             if (phase == 2) {
                 // my rows' entries of column la AFTER this pivot, computed by the lane that holds them
@@ -698,12 +732,18 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
                 }
                 __syncthreads();
             }
+            YSTAMP(7); // my rows' entries of the next entering column
             candidate(phase);
+            YSTAMP(8);
             const int cg = sh_cg;
             finish_rows(cg, true, 0, R);
+            YSTAMP(9);
             publish_stores();
+            YSTAMP(10);
             if constexpr (SPLIT > 0) finish_rows(cg, false, 0, SPLIT); // (while the stores drain)
+            YSTAMP(11);
             publish_flag();
+            YSTAMP(12);
             finish_rows(cg, false, SPLIT, R); // (while the flags travel)
         } else {
             finish_rows(-1, false, 0, R);
@@ -718,7 +758,20 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
         }
         // (no barrier here: the next write to sh_val / sh_nq comes after the gather's barrier, which every
         // wave reaches only after it has finished reading them)
+        YSTAMP(13); // the other rows
     }
+#ifdef YALPS_STAMPS
+    if (tid == 0 && d.dbg) {
+        unsigned long long t1, r1;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1)::"memory");
+        unsigned long long *out = d.dbg + (size_t)b * STAMP_WORDS;
+#pragma unroll
+        for (int k = 0; k < 20; k++) out[k] += st_acc[k];
+        out[20] += (unsigned long long)done;
+        out[21] += t1 - st_t0;
+        out[22] += r1 - st_r0;
+    }
+#endif
 
     // ---------------- leave: tableau to the other buffer, state, basis ---------------------------
     double *matB = d.mat[mbuf ^ 1];

@@ -181,12 +181,13 @@ __global__ __launch_bounds__(T) void stream_kernel(Desc d, int parity, int chunk
         if (tid < NB) {
             unsigned long long f = 0;
             unsigned spins = 0;
+            unsigned long long spin_t0 = 0;
             double2 rec;
             for (;;) {
                 rec = ld16_sc1_one(d.rc_flag[par] + 2 * tid);
                 f = (unsigned long long)__double_as_longlong(rec.y);
                 if ((unsigned)(f >> 32) == epoch) break;
-                if (++spins > (1u << 22) || __hip_atomic_load(d.rc_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                if (spin_expired(spins, spin_t0, d.rc_err)) {
                     sh_fail = 1;
                     __hip_atomic_store(d.rc_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
@@ -263,10 +264,11 @@ __global__ __launch_bounds__(T) void stream_kernel(Desc d, int parity, int chunk
                 if (tid == 0) {
                     unsigned long long v = 0;
                     unsigned spins = 0;
+            unsigned long long spin_t0 = 0;
                     for (;;) {
                         v = __hip_atomic_load(d.rc_verdict + par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if ((unsigned)(v >> 32) == epoch) break;
-                        if (++spins > (1u << 22) || __hip_atomic_load(d.rc_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        if (spin_expired(spins, spin_t0, d.rc_err)) {
                             sh_fail = 1;
                             __hip_atomic_store(d.rc_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             break;

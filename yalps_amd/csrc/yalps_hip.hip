@@ -27,6 +27,11 @@
 // first-wins comparisons in every scan.
 #include <hip/hip_runtime.h>
 
+#include <fcntl.h>
+#include <sys/file.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <chrono>
 #include <climits>
@@ -102,6 +107,9 @@ std::vector<RVariant> variants_of(std::initializer_list<PersistentTable> tables)
     return out;
 }
 const std::vector<RVariant> kResident = variants_of({yalps_resident_table_a(), yalps_resident_table_b()});
+// resident2_kernel<T, J, R>: the same shapes with the second-generation pivot loop (resident2_kernel.cuh); used where it
+// exists unless YALPS_HIP_RESIDENT_GEN=1 asks for the first generation (A/B measurements, tests of both)
+const std::vector<RVariant> kResident2 = variants_of({yalps_resident2_table_a(), yalps_resident2_table_b()});
 // The same with up to XROWS more rows per workgroup parked in LDS (tableaux a little beyond the register files):
 // tried when no variant above fits; R = register rows, the LDS rows are what is missing.
 const std::vector<RVariant> kResidentLds = variants_of({yalps_resident_lds_table()});
@@ -127,6 +135,40 @@ int fail(int code, const std::string &msg) {
 std::mutex &persistent_mutex(int device) {
     static std::mutex mu[64];
     return mu[device & 63];
+}
+constexpr int PERSISTENT_RETRY_AFTER = 8;
+// The same between processes: an advisory lock on one file per physical device (named by its PCI bus id), held from a
+// persistent launch to its completion.  Two processes of this library on one GPU (ranks rehearsing on a shared card, a
+// Node process next to a Python one) then never interleave their grids.  Kernels of other software are not covered:
+// against those the launch has its bounded waits (common.cuh spin_expired) and the fall-back.
+struct DeviceLock {
+    int fd;
+    explicit DeviceLock(int fd_) : fd(fd_) {
+        if (fd >= 0)
+            while (flock(fd, LOCK_EX) != 0 && errno == EINTR) {
+            }
+    }
+    ~DeviceLock() {
+        if (fd >= 0) (void)flock(fd, LOCK_UN);
+    }
+    DeviceLock(const DeviceLock &) = delete;
+    DeviceLock &operator=(const DeviceLock &) = delete;
+};
+int open_device_lock(int device) {
+    char bus[64] = "";
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) std::snprintf(bus, sizeof bus, "dev%d", device);
+    for (char *p = bus; *p; p++)
+        if (*p == ':' || *p == '/' || *p == '.') *p = '_';
+    const char *dir = std::getenv("YALPS_HIP_LOCK_DIR");
+    const std::string path = std::string(dir && *dir ? dir : "/tmp") + "/yalps_hip_" + bus + ".lock";
+    const int fd = open(path.c_str(), O_RDWR | O_CREAT | O_CLOEXEC, 0666);
+    if (fd < 0) {
+        std::fprintf(stderr, "yalps_hip: cannot open %s (%s): persistent launches are not serialised between processes\n",
+                     path.c_str(), std::strerror(errno));
+        return -1;
+    }
+    (void)fchmod(fd, 0666); // (another user's process must be able to open it too; the umask may have narrowed the mode)
+    return fd;
 }
 constexpr size_t LDS_DYNAMIC_MAX = 160 * 1024 - 2048;
 int allow_big_lds(int device, const void *fn) {
@@ -164,8 +206,15 @@ struct yalps_ctx {
     bool nt_stores = false;
     bool resident = true; // use the on-chip resident kernel when the tableau fits (YALPS_HIP_RESIDENT=0: never)
     bool inplace = true;  // use the persistent in-place kernel beyond that (YALPS_HIP_INPLACE=0: never)
+    // A persistent launch whose hand-off gave up (its grid was not co-resident: a foreign kernel held CUs) switches its
+    // path off for the next PERSISTENT_RETRY_AFTER solves of this context, not for good; every give-up is counted and
+    // reported (stderr once per event, yalps_tableau_info).
+    int resident_skip = 0, inplace_skip = 0; // solves left before the path is tried again
+    int64_t giveups = 0;
+    int lock_fd = -1; // per-device lock file shared by every process that uses this library (persistent launches take turns)
     int resident_chunk = RESIDENT_CHUNK; // pivots per resident launch (YALPS_HIP_RESIDENT_CHUNK)
-    int resident_fault = 0; // test hook: treat the N-th resident launch as failed (YALPS_HIP_RESIDENT_FAULT=N)
+    int resident_fault = 0; // test hook: treat the N-th persistent launch on this context as failed (YALPS_HIP_RESIDENT_FAULT=N)
+    int64_t persistent_launches = 0;
     int num_cus = 256;
     int max_blocks = 256; // workgroups per launch (one per CU by default)
     // single-workgroup LDS path for small tableaux (YALPS_HIP_SMALL=0: never)
@@ -188,6 +237,7 @@ struct yalps_tableau {
                                  // on dense tableaux (60 vs 74 us/pivot at 1025x16385, 130 vs 126 at 4097x9001) and skips untouched rows
     int shard_parity = 0;
     RVariant rvar{0, 0, 0, nullptr}; // resident kernel variant, fn == nullptr: tableau does not fit
+    int rgen = 1;                    // 2: rvar is a resident2_kernel
     void *rc_sync = nullptr; // flags[2], verdict[2], error word of the persistent kernels (one allocation)
     size_t rc_sync_bytes = 0;
     RVariant svar{0, 0, 0, nullptr}; // stream_kernel variant (persistent, in place)
@@ -195,6 +245,8 @@ struct yalps_tableau {
     bool sattr_check = false;
     size_t sshmem = 0;
     bool sattr = false;
+    bool occupancy_warned = false;
+    int64_t giveups = 0;             // persistent launches of this tableau that gave up waiting (fell back)
     int last_path = 0;               // what the last solve ran: 1 resident, 2 streaming, 4 small, 8 in place (sums: fallbacks)
     int64_t last_launches = 0;       // kernel launches of the last solve that did work (resident: chunks)
     size_t rshmem = 0;
@@ -404,6 +456,7 @@ static int32_t ctx_create(int32_t device, void *ext_stream, bool adopt, yalps_ct
     if (c->small_hist_cap < 1) c->small_hist_cap = 1;
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->small_res), sizeof(SmallResult), hipHostMallocDefault));
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; // measured 1-2 % faster in the pivot loop at 2049^2 and 4097^2
+    c->lock_fd = env_int("YALPS_HIP_LOCK", 1) ? open_device_lock(device) : -1;
     c->max_blocks = env_int("YALPS_HIP_BLOCKS", prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
     if (c->max_blocks < 1) c->max_blocks = 1;
     if (c->max_blocks > MAX_BLOCKS) c->max_blocks = MAX_BLOCKS;
@@ -439,6 +492,7 @@ void yalps_ctx_destroy(yalps_ctx *c) {
     if (c->small_res) (void)hipHostFree(c->small_res);
     if (c->small_blob) (void)hipHostFree(c->small_blob);
     if (c->small_hist) (void)hipFree(c->small_hist);
+    if (c->lock_fd >= 0) (void)close(c->lock_fd);
     delete c;
 }
 
@@ -532,6 +586,12 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
                 t->rvar = v;
             }
         }
+        if (t->rvar.fn && env_int("YALPS_HIP_RESIDENT_GEN", 2) >= 2)
+            for (const RVariant &v : kResident2)
+                if (v.T == t->rvar.T && v.J == t->rvar.J && v.R == t->rvar.R) {
+                    t->rvar = v;
+                    t->rgen = 2;
+                }
         if (!t->rvar.fn && env_int("YALPS_HIP_LDS_ROWS", 1)) { // a little too tall: park the rows that are missing in LDS
             const int xl_ofs = (2 * (width + hcap) + 3) / 4 * 4;
             int best_extra = INT_MAX;
@@ -594,6 +654,10 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
         HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&t->host_ctl), 16 + 2 * sizeof(YState) + sizeof(YConst), hipHostMallocDefault));
     }
     HIP_TRY(hipHostMalloc(&t->host_state, sizeof(YState) * 4 + sizeof(YConst), hipHostMallocDefault)); // 4 slots + YConst
+#ifdef YALPS_STAMPS
+    HIP_TRY(hipMalloc(&d.dbg, sizeof(unsigned long long) * STAMP_WORDS * MAX_BLOCKS));
+    HIP_TRY(hipMemsetAsync(d.dbg, 0, sizeof(unsigned long long) * STAMP_WORDS * MAX_BLOCKS, s));
+#endif
     for (int k = 0; k < 4; k++) HIP_TRY(hipEventCreateWithFlags(&t->slot_ev[k], hipEventDisableTiming));
     HIP_TRY(hipStreamSynchronize(s));
     *out = t;
@@ -626,7 +690,7 @@ void yalps_tableau_destroy(yalps_tableau *t) {
     void *bufs[] = {d.mat[0], d.mat[1], d.rhs[0], d.rhs[1], t->perm_block ? nullptr : d.pos, t->perm_block ? nullptr : d.var, t->perm_block,
                     t->ctl_block ? nullptr : d.st, t->ctl_block ? nullptr : d.cst, t->ctl_block, d.rc_rows[0], d.rc_rows[1], t->perm_backup,
                     d.rc_key[0], d.rc_key[1], d.gen_prow, d.gen_scal, d.part_ratio[0], d.part_ratio[1], d.part_rhs[0], d.part_rhs[1],
-                    t->hist[0], t->hist[1], t->cells};
+                    t->hist[0], t->hist[1], t->cells, d.dbg};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (t->host_state) (void)hipHostFree(t->host_state);
@@ -643,7 +707,7 @@ int32_t yalps_tableau_info(const yalps_tableau *t, char *buf, int32_t len) {
     if (!t || !buf || len < 1) return fail(YALPS_E_ARG, "yalps_tableau_info: bad argument");
     char res[96] = "none", inp[64] = "none";
     if (t->rvar.fn)
-        std::snprintf(res, sizeof res, "resident_kernel<%d,%d,%d%s> chunk=%d lds_rows=%d", t->rvar.T, t->rvar.J, t->rvar.R,
+        std::snprintf(res, sizeof res, "resident%s_kernel<%d,%d,%d%s> chunk=%d lds_rows=%d", t->rgen == 2 ? "2" : "", t->rvar.T, t->rvar.J, t->rvar.R,
                       t->d.extra ? ",lds" : t->rvar_tag.fn ? ",tag" : "", RESIDENT_CHUNK, t->d.extra);
     if (t->svar.fn) std::snprintf(inp, sizeof inp, "stream_kernel<%d,%d>", t->svar.T, t->svar.J);
     char str[64];
@@ -651,8 +715,10 @@ int32_t yalps_tableau_info(const yalps_tableau *t, char *buf, int32_t len) {
         std::snprintf(str, sizeof str, "wide_kernel<%d,%d>", t->var.T, t->var.J);
     else
         std::snprintf(str, sizeof str, "pivot_kernel<%d,%d,%d>", t->var.T, t->var.J, t->var.R);
-    std::snprintf(buf, (size_t)len, "streaming=%s workgroups=%d resident=%s inplace=%s last_path=%s last_resident_launches=%lld", str,
-                  t->nb, res, inp,
+    std::snprintf(buf, (size_t)len, "streaming=%s workgroups=%d resident=%s inplace=%s giveups=%lld resident_off_for=%d inplace_off_for=%d "
+                  "last_path=%s last_resident_launches=%lld", str,
+                  t->nb, res, inp, (long long)t->giveups, t->ctx->resident ? t->ctx->resident_skip : -1,
+                  t->ctx->inplace ? t->ctx->inplace_skip : -1,
                   t->last_path == 1 ? "resident" : t->last_path == 2 ? "streaming" : t->last_path == 3 ? "resident+streaming"
                   : t->last_path == 4 ? "small" : t->last_path == 8 ? "inplace" : t->last_path == 10 ? "inplace+streaming"
                   : t->last_path == 9 ? "resident+inplace" : t->last_path == 11 ? "resident+inplace+streaming"
@@ -661,10 +727,26 @@ int32_t yalps_tableau_info(const yalps_tableau *t, char *buf, int32_t len) {
     return 0;
 }
 
+int32_t yalps_tableau_debug_stamps(yalps_tableau *t, uint64_t *out, int32_t cap_words, int32_t reset) {
+#ifdef YALPS_STAMPS
+    if (!t || !t->d.dbg || (cap_words > 0 && !out)) return fail(YALPS_E_ARG, "yalps_tableau_debug_stamps: bad argument");
+    HIP_TRY(hipSetDevice(t->ctx->device));
+    HIP_TRY(hipStreamSynchronize(t->ctx->stream));
+    const int32_t words = t->nb * STAMP_WORDS < cap_words ? t->nb * STAMP_WORDS : cap_words;
+    if (words > 0) HIP_TRY(hipMemcpy(out, t->d.dbg, sizeof(uint64_t) * (size_t)words, hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(t->d.dbg, 0, sizeof(unsigned long long) * STAMP_WORDS * MAX_BLOCKS));
+    return words;
+#else
+    (void)t, (void)out, (void)cap_words, (void)reset;
+    return fail(YALPS_E_ARG, "yalps_tableau_debug_stamps: this is not the diagnostic build (-DYALPS_STAMPS)");
+#endif
+}
+
 int32_t yalps_tableau_upload(yalps_tableau *t, const double *matrix, int32_t height, const int32_t *pos,
                              const int32_t *var) {
     if (!t || !matrix || !pos || !var) return fail(YALPS_E_ARG, "yalps_tableau_upload: NULL argument");
     if (height < 1 || height > t->d.hcap) return fail(YALPS_E_ARG, "yalps_tableau_upload: height exceeds capacity");
+    if (t->d.nshards > 1) return fail(YALPS_E_ARG, "yalps_tableau_upload: tableau is sharded; create a new one");
     HIP_TRY(hipSetDevice(t->ctx->device));
     hipStream_t s = t->ctx->stream;
     const Desc &d = t->d;
@@ -675,7 +757,6 @@ int32_t yalps_tableau_upload(yalps_tableau *t, const double *matrix, int32_t hei
     if (d.n > 0)
         HIP_TRY(hipMemcpy2DAsync(d.mat[0], sizeof(double) * d.pitch, matrix + 1, sizeof(double) * d.w,
                                  sizeof(double) * d.n, height, hipMemcpyHostToDevice, s));
-    if (t->d.nshards > 1) return fail(YALPS_E_ARG, "yalps_tableau_upload: tableau is sharded; create a new one");
     const size_t nperm = sizeof(int32_t) * (size_t)(d.w + height);
     t->perm_len = d.w + height;
     t->d.perm_len = t->perm_len;
@@ -1035,10 +1116,13 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
     //     fits on chip, else the in-place streaming kernel
     // (fall-back order: resident -> in place -> one launch per pivot; a path that fails is not tried again on this context)
     int64_t hist_have = 0; // checkCycles: pivots recorded in the current phase at the next launch's start
+    // (a path switched off by a give-up comes back after PERSISTENT_RETRY_AFTER solves)
+    const bool resident_on = c->resident && (c->resident_skip == 0 || --c->resident_skip == 0);
+    const bool inplace_on = c->inplace && (c->inplace_skip == 0 || --c->inplace_skip == 0);
     for (int attempt = 0; attempt < 2 && !finished; attempt++) {
         const bool persistent_ok = t->d.nshards == 1;
-        const bool use_resident = persistent_ok && c->resident && t->rvar.fn; // (checkCycles: one more exchange per pivot)
-        const bool use_stream = persistent_ok && !use_resident && c->inplace && (checkCycles ? t->svar_check.fn : t->svar.fn);
+        const bool use_resident = persistent_ok && resident_on && c->resident_skip == 0 && t->rvar.fn; // (checkCycles: one more exchange per pivot)
+        const bool use_stream = persistent_ok && !use_resident && inplace_on && c->inplace_skip == 0 && (checkCycles ? t->svar_check.fn : t->svar.fn);
         if (!use_resident && !use_stream) break;
         const bool in_place = use_stream;
         const RVariant &pv = in_place ? (checkCycles ? t->svar_check : t->svar) : t->rvar_tag.fn ? t->rvar_tag : t->rvar;
@@ -1051,6 +1135,23 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
                 sattr = true;
             else
                 t->rshmem = shmem;
+        }
+        // every workgroup of the grid must be resident at once: ask the runtime what fits (registers, LDS, waves) before
+        // launching a grid that would wait for workgroups that cannot start
+        {
+            int per_cu = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(pv.fn), pv.T, shmem));
+            if (per_cu < 1 || t->nb > c->num_cus * per_cu) {
+                if (!t->occupancy_warned)
+                    std::fprintf(stderr, "yalps_hip: %s<%d,%d,%d>: %d workgroups do not fit on %d CUs x %d; using the next path\n",
+                                 in_place ? "stream_kernel" : "resident_kernel", pv.T, pv.J, pv.R, t->nb, c->num_cus, per_cu);
+                t->occupancy_warned = true;
+                if (in_place)
+                    t->svar.fn = t->svar_check.fn = nullptr;
+                else
+                    t->rvar.fn = t->rvar_tag.fn = nullptr;
+                continue;
+            }
         }
         int chunk = c->resident_chunk;
         if (in_place) { // bound a launch to ~0.25 s: a pivot streams at most the whole tableau (~6 TB/s), never under ~8 us
@@ -1095,9 +1196,11 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
                 // (threads) could each get half of the CUs and wait for the rest until their bounded spins give up:
                 // within this process, one at a time per device, from the launch to its completion.
                 std::lock_guard<std::mutex> one_grid(persistent_mutex(c->device));
+                DeviceLock one_grid_of_all_processes(c->lock_fd);
                 pv.fn<<<dim3(t->nb), dim3(pv.T), shmem, s>>>(t->d, parity, chunk);
                 t->last_path |= in_place ? 8 : 1;
                 t->last_launches++;
+                c->persistent_launches++;
                 HIP_TRY(hipGetLastError());
                 // [error word | st0 | st1] are adjacent: one copy back
                 HIP_TRY(hipMemcpyAsync(t->host_ctl, t->d.rc_err, 16 + 2 * sizeof(YState), hipMemcpyDeviceToHost, s));
@@ -1110,7 +1213,7 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
                     HIP_TRY(hipMemcpyAsync(stage + f_ncol, t->perm_block, sizeof(int32_t) * (size_t)t->perm_cap + f_nperm, hipMemcpyDeviceToHost, s));
                 }
                 HIP_TRY(hipStreamSynchronize(s));
-                if (fetch && *reinterpret_cast<int32_t *>(t->host_ctl) == 0 && !(c->resident_fault > 0 && t->last_launches == c->resident_fault) &&
+                if (fetch && *reinterpret_cast<int32_t *>(t->host_ctl) == 0 && !(c->resident_fault > 0 && c->persistent_launches == c->resident_fault) &&
                     reinterpret_cast<YState *>(t->host_ctl + 16)[parity ^ 1].status != RUNNING) {
                     const char *stage = static_cast<const char *>(t->pin_out);
                     std::memcpy(t->fetch_col0, stage, f_ncol);
@@ -1126,13 +1229,19 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
                 std::fprintf(stderr, "yalps_hip: persistent launch %lld err=%d status=%d phase=%d iter=%g pivots=%lld result=%g mbuf=%d chunk=%d\n",
                              (long long)t->last_launches, *herr, hs.status, hs.phase, hs.iter, (long long)hs.pivots, hs.result, hs.mbuf, chunk);
             }
-            if (*herr || (c->resident_fault > 0 && t->last_launches == c->resident_fault)) {
-                // a workgroup gave up waiting (grid not co-resident?): never again on this context; carry on with the
-                // launch-per-pivot kernels from the last consistent state (st[parity]; in place: the copy made above)
+            if (*herr || (c->resident_fault > 0 && c->persistent_launches == c->resident_fault)) {
+                // a workgroup gave up waiting (grid not co-resident: somebody else's kernel holds CUs): carry on with the
+                // next path from the last consistent state (st[parity]; in place: the copy made above), say so, and
+                // leave this path alone for the next few solves of this context
+                c->giveups++;
+                t->giveups++;
+                std::fprintf(stderr, "yalps_hip: %s launch gave up waiting for its grid (device shared with other work?); "
+                                     "falling back for this and the next %d solves (event %lld on this context)\n",
+                             in_place ? "stream_kernel" : "resident_kernel", PERSISTENT_RETRY_AFTER, (long long)c->giveups);
                 if (in_place)
-                    c->inplace = false;
+                    c->inplace_skip = PERSISTENT_RETRY_AFTER + 1;
                 else
-                    c->resident = false;
+                    c->resident_skip = PERSISTENT_RETRY_AFTER + 1;
                 if (backup)
                     HIP_TRY(hipMemcpyAsync(t->perm_block, t->perm_backup, sizeof(int32_t) * 2 * (size_t)t->perm_cap, hipMemcpyDeviceToDevice, s));
                 YState last;
@@ -1506,10 +1615,16 @@ int32_t yalps_batch_solve(yalps_batch *b, int32_t count, const int32_t *cut_offs
                           int32_t *status_out, double *result_out, int64_t *pivots_out, float *gpu_ms_out) {
     if (!b || count < 1 || count > b->max_nodes || !cut_offsets || !cut_sign || !cut_var || !cut_value)
         return fail(YALPS_E_ARG, "yalps_batch_solve: bad argument");
-    const int32_t total = cut_offsets[count];
+    // everything the kernel will index with is checked here, before anything is enqueued (like apply_cuts_impl)
+    if (cut_offsets[0] != 0) return fail(YALPS_E_ARG, "yalps_batch_solve: cut_offsets[0] must be 0");
     for (int32_t i = 0; i < count; i++)
-        if (cut_offsets[i + 1] - cut_offsets[i] > b->max_cuts || cut_offsets[i + 1] < cut_offsets[i])
-            return fail(YALPS_E_ARG, "yalps_batch_solve: a node has more cuts than the batch was created for");
+        if (cut_offsets[i + 1] < cut_offsets[i] || cut_offsets[i + 1] - cut_offsets[i] > b->max_cuts)
+            return fail(YALPS_E_ARG, "yalps_batch_solve: cut_offsets must not decrease, and a node has at most max_cuts cuts");
+    const int32_t total = cut_offsets[count];
+    if ((int64_t)total > (int64_t)b->max_nodes * b->max_cuts) return fail(YALPS_E_ARG, "yalps_batch_solve: more cuts than the batch has room for");
+    for (int32_t i = 0; i < total; i++)
+        if (cut_var[i] < 0 || cut_var[i] >= b->d.w + b->d.h0)
+            return fail(YALPS_E_ARG, "yalps_batch_solve: cut on an unknown variable");
     yalps_ctx *c = b->ctx;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = c->stream;
