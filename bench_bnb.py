@@ -125,14 +125,20 @@ def main():
         assert seq[i][0] == sts[i] and seq[i][2] == int(pivs[i])
         assert (math.isnan(seq[i][1]) and math.isnan(ress[i])) or seq[i][1] == ress[i]
 
-    # oracle check on a sample (bit-exact whole tableau)
+    # oracle check on a sample (bit-exact whole tableau); the oracle's own time on those nodes (applyCuts on the host +
+    # simplex, one core) is the CPU baseline of this config
     orc = _oracle.load()
     step = max(1, len(nodes) // max(args.check, 1))
     checked = 0
+    cpu_s, cpu_pivots = 0.0, 0
     for i in range(0, len(nodes), step):
+        t0 = time.perf_counter()
         cur = BC.apply_cuts(root, buf, nodes[i])
         mm, pp, vv = cur.matrix.copy(), cur.position_of_variable.copy(), cur.variable_at_position.copy()
+        t1 = time.perf_counter()
         est, eres, epiv, _ = orc.simplex(mm, cur.width, cur.height, pp, vv)
+        cpu_s += time.perf_counter() - t1
+        cpu_pivots += epiv
         gm, _, gp, gv = batch.download(i, cur.height, matrix=True)
         assert est == sts[i] and epiv == int(pivs[i]) and np.array_equal(gm.view(np.int64), mm.view(np.int64))
         assert np.array_equal(gp, pp) and np.array_equal(gv, vv)
@@ -158,7 +164,11 @@ def main():
                   "status_counts": {s: sts.count(s) for s in sorted(set(sts))}},
         "one_at_a_time": {"nodes": k, "wall_ms": 1e3 * wall_seq, "nodes_per_s": k / wall_seq},
         "speedup_vs_one_at_a_time": (all_nodes / wall_batch) / (k / wall_seq),
-        "oracle_checked_nodes": checked}))
+        "oracle_checked_nodes": checked,
+        "cpu_baseline": {"value": checked / cpu_s, "unit": "nodes/s", "cores": 1, "kind": "port",
+                         "pivots_per_s": cpu_pivots / cpu_s,
+                         "sample": "%d of this rank's nodes (every %d-th), oracle/simplex_oracle.c simplex() on the host-built node "
+                                   "tableau (applyCuts not timed), %.2f s, host has %d cores" % (checked, step, cpu_s, os.cpu_count())}}))
 
 
 if __name__ == "__main__":

@@ -33,8 +33,10 @@ README_MS = {"Monster 2": 53.95, "Monster Problem": 1.85, "Vendor Selection": 29
 
 
 def main():
-    from tests import _cases as K, _golden as G
+    from tests import _cases as K, _golden as G, _oracle
+    from tests.test_host_model import oracle_backend
     from yalps_amd import _native, model as M, mps, solve as S
+    orc = _oracle.load()
     netlib = {b["name"]: b for b in mps.read_benchmarks(os.path.join(G.GOLDEN, "netlib"))}
     rows, benches = [], []
     for name, ref_ms in README_MS.items():
@@ -55,6 +57,13 @@ def main():
             st, res, piv = _native.simplex_host(m, t.width, t.height, pos, var, precision=opt["precision"],
                                                 max_pivots=opt["maxPivots"], check_cycles=opt["checkCycles"])
             lp.append(time.perf_counter() - t0)
+        # the same root LP on one host core: the CPU oracle (the scalar port of src/simplex.ts) on the same initial tableau
+        m, pos, var = t.matrix.copy(), t.position_of_variable.copy(), t.variable_at_position.copy()
+        t0 = time.perf_counter()
+        cst, cres, cpiv, _ = orc.simplex(m, t.width, t.height, pos, var, precision=opt["precision"], max_pivots=opt["maxPivots"],
+                                         check_cycles=opt["checkCycles"])
+        cpu_lp = time.perf_counter() - t0
+        assert (cst, cpiv) == (st, piv)
         cells = M.tableau_model(mdl, sparse=True).tableau.cells
         sp = []
         for _ in range(5):
@@ -66,7 +75,9 @@ def main():
         row = {"problem": name, "tableau": "%dx%d" % (t.height, t.width), "integers": len(tm.integers),
                "root_status": st, "root_pivots": piv, "lp_ms": round(1e3 * min(lp), 3), "lp_sparse_ms": round(1e3 * min(sp), 3),
                "cells": int(cells[0].size),
-               "us_per_pivot": round(1e6 * min(lp) / max(piv, 1), 2), "reference_solve_ms_readme": ref_ms}
+               "us_per_pivot": round(1e6 * min(lp) / max(piv, 1), 2), "reference_solve_ms_readme": ref_ms,
+               "cpu_baseline": {"value": round(1e3 * cpu_lp, 3), "unit": "ms per simplex() of the root LP", "cores": 1, "kind": "port",
+                                "sample": "oracle/simplex_oracle.c on the same initial tableau, %d pivots" % cpiv}}
         if tm.integers:
             for label, nb, dev, nat in (("milp_sequential_ms", 0, False, False), ("milp_batched_ms", 32, False, False),
                                         ("milp_device_nodes_ms", 0, True, False), ("milp_native_ms", 0, True, True),
@@ -77,6 +88,22 @@ def main():
                     sol = S.solve(mdl, opt, node_batch=nb, device_nodes=dev, native=nat)
                     ts.append(time.perf_counter() - t0)
                 row[label] = round(1e3 * min(ts), 2)  # includes the Python host (tableau build, heap, cuts)
+            # the whole branch and cut with every node LP on one host core: the same Python driver as milp_sequential_ms
+            # around the CPU oracle; cpu_simplex_ms = the time inside the oracle alone (what the GPU replaces)
+            inside = [0.0, 0]
+
+            def cpu_backend(tableau, options, _b=oracle_backend(orc)):
+                t0 = time.perf_counter()
+                out = _b(tableau, options)
+                inside[0] += time.perf_counter() - t0
+                inside[1] += 1
+                return out
+            t0 = time.perf_counter()
+            csol = S._solve_with(cpu_backend, mdl, opt)
+            row["milp_cpu_sequential_ms"] = round(1e3 * (time.perf_counter() - t0), 2)
+            row["cpu_baseline_milp"] = {"value": round(1e3 * inside[0], 2), "unit": "ms inside simplex() over the whole branch and cut",
+                                        "cores": 1, "kind": "port", "sample": "%d simplex() calls (root + nodes), oracle/simplex_oracle.c" % inside[1]}
+            assert csol["status"] == sol["status"]
             row["objective_ok"] = bool(K.result_is_optimal(sol["result"], expected, S.default_options | {"tolerance": opt.get("tolerance", 0)}))
         rows.append(row)
     from yalps_amd import benchmark as B

@@ -168,6 +168,26 @@ int32_t yalps_shard_select(yalps_tableau *t, double *send_dev);
 int32_t yalps_shard_apply(yalps_tableau *t, const double *gathered_dev);
 int32_t yalps_shard_poll(yalps_tableau *t, int32_t *status_out, double *result_out, int64_t *pivots_out);
 
+/* The same loop run natively, exchange included: no host-language call per pivot.  A yalps_comm is this rank's end of
+ * the exchange: RCCL over xGMI (looked up at run time; yalps_comm_unique_id on rank 0 yields the 128 bytes that every
+ * rank passes to yalps_comm_create, carried between the processes by the host's own channel), or -- for hosts with a
+ * channel of their own, and for tests -- a host callback that all-gathers `doubles_per_rank` doubles per rank between
+ * host buffers (send_host: mine; recv_host: nranks slots in rank order; returns 0).
+ * yalps_shard_run = yalps_shard_begin + { select, all-gather, apply } until the replicated status is final, the status
+ * read back every `check_every` pivots; with RCCL the batch of check_every pivots is captured once into a hipGraph and
+ * replayed.  Returns 0 or a negative error; *status_out / *result_out follow src/simplex.ts's return protocol and are
+ * identical on every rank. */
+typedef struct yalps_comm yalps_comm;
+typedef int32_t (*yalps_allgather_fn)(void *user, const double *send_host, double *recv_host, int64_t doubles_per_rank);
+int32_t yalps_comm_unique_id(void *id128);
+int32_t yalps_comm_create(yalps_ctx *ctx, const void *id128, int32_t rank, int32_t nranks, yalps_comm **out);
+int32_t yalps_comm_create_host(yalps_ctx *ctx, yalps_allgather_fn fn, void *user, int32_t rank, int32_t nranks,
+                               yalps_comm **out);
+void yalps_comm_destroy(yalps_comm *c);
+int32_t yalps_comm_info(const yalps_comm *c, char *buf, int32_t len);
+int32_t yalps_shard_run(yalps_tableau *t, yalps_comm *c, double precision, double maxPivots, int32_t check_every,
+                        int32_t *status_out, double *result_out, int64_t *pivots_out, float *gpu_ms_out);
+
 /* ---- batched branch-and-cut node evaluation (BASELINE config 4) ---------------
  * src/branchAndCut.ts:126-127 evaluates every node as simplex(applyCuts(root, cuts)); nodes are
  * independent given the root.  A batch keeps the root's optimal tableau resident, builds each

@@ -1,5 +1,6 @@
 """Worker of the multi-process row-sharded tests: one rank of a gloo (or nccl) group.
-usage: python -m tests._shard_worker <numpy|hip> <M> <N> <seed> <out.npz> [max_pivots [digest]]
+usage: python -m tests._shard_worker <numpy|hip|hip-native> <M> <N> <seed> <out.npz> [max_pivots [digest]]
+(hip-native: the library's own loop, yalps_shard_run, with the host transport carried by gloo)
 (RANK/WORLD_SIZE/MASTER_* in env).  `digest`: instead of the assembled tableau, rank 0 saves the SHA-256 of the
 objective row and of every rank's block of rows (full-size runs: the tableau is 2.1 GB)."""
 import os
@@ -35,9 +36,15 @@ def main():
         ops = NumpyShardOps(local, w, bounds, rank, h, ident, ident.copy())
     else:
         ops = sharded.HipShardOps(local, w, bounds, rank, h, ident, ident.copy(), device=0)
-    comm = sharded.TorchComm()
     del m
-    status, result, pivots = sharded.sharded_simplex(ops, comm, max_pivots=max_pivots, check_every=8 if max_pivots > 8 else 1)
+    if kind == "hip-native":
+        ncomm = sharded.native_comm(ops.ctx, rank, world, transport="host")
+        status, result, pivots = sharded.sharded_simplex_native(ops, ncomm, max_pivots=max_pivots, check_every=8)
+        assert ncomm.info()["transport"] == "host" and int(ncomm.info()["collectives"]) >= pivots
+        ncomm.close()
+    else:
+        comm = sharded.TorchComm()
+        status, result, pivots = sharded.sharded_simplex(ops, comm, max_pivots=max_pivots, check_every=8 if max_pivots > 8 else 1)
     lm, pos, var = ops.download()
     if digest:
         import hashlib

@@ -313,10 +313,14 @@ def test_small_path_boundary(nat, ctx):
             t.close()
 
 
-def test_golden_cases_without_small_path(nat, oracle, monkeypatch):
+@pytest.mark.parametrize("tag", ["1", "0"], ids=["tagged-rows", "second-generation-loop"])
+def test_golden_cases_without_small_path(nat, oracle, monkeypatch, tag):
     """The multi-workgroup kernels (resident, streaming) on the small golden tableaux too: the same
-    records as test_dropin_matches_reference_golden on a context created with YALPS_HIP_SMALL=0."""
+    records as test_dropin_matches_reference_golden on a context created with YALPS_HIP_SMALL=0; once with the tagged
+    candidate rows these shapes take by default, once with YALPS_HIP_TAG=0 through resident2_kernel (sparse rows with
+    entries around the 1e-16 flush: its non-zero-mask path, phase 1 and checkCycles included)."""
     monkeypatch.setenv("YALPS_HIP_SMALL", "0")
+    monkeypatch.setenv("YALPS_HIP_TAG", tag)
     c = nat.Context(0)
     paths = set()
     try:
@@ -371,9 +375,12 @@ def test_small_path_check_cycles_history_growth(nat, oracle, monkeypatch):
                                         (5000, 700, "resident_kernel<512,1,24>"), (1300, 4300, "resident_kernel<512,5,6>"), (7000, 300, "resident_kernel<512,1,32>"), (9000, 250, "resident_kernel<512,1,40>"),
                                         (2600, 2600, "resident_kernel<512,3,12>"), (900, 5800, "resident_kernel<512,6,4>"),
                                         (2100, 2480, "resident_kernel<512,3,9>")])
-def test_resident_variants_match_oracle(nat, ctx, oracle, M, N, kernel):
+@pytest.mark.parametrize("gen", ["1", "2"])
+def test_resident_variants_match_oracle(nat, ctx, oracle, monkeypatch, M, N, kernel, gen):
     """The odd-J and tall variants of the resident kernel, 200 pivots each against the oracle
-    (maxPivots exhausted -> "cycled" with the tableau as it stands), bit for bit."""
+    (maxPivots exhausted -> "cycled" with the tableau as it stands), bit for bit; gen 2: with the second-generation pivot
+    loop (resident2_kernel) where that shape has one, the first generation elsewhere."""
+    monkeypatch.setenv("YALPS_HIP_RESIDENT_GEN", gen)  # (read when the tableau is created)
     w, h = N + 1, M + 1
     m = nat.dense_lp(M, N, 7)
     m[(h // 3) * w:(h // 3 + 1) * w] *= -1.0  # a row "-a x <= -b": phase 1 first
@@ -389,7 +396,8 @@ def test_resident_variants_match_oracle(nat, ctx, oracle, M, N, kernel):
         got, gpos, gvar = t.download()
     finally:
         t.close()
-    assert info["last_path"] == "resident" and info["resident"].startswith(kernel), info
+    names = (kernel,) if gen == "1" else (kernel, kernel.replace("resident_kernel", "resident2_kernel"))
+    assert info["last_path"] == "resident" and info["resident"].startswith(names), info
     assert (status, npiv) == (est, epiv) and G.same_number(result, eres)
     assert np.array_equal(got.view(np.int64), ref.view(np.int64))
     assert np.array_equal(gpos, rpos) and np.array_equal(gvar, rvar)
@@ -519,8 +527,10 @@ def test_resident_tagged_rows_equal_the_flag_protocol(nat, ctx, oracle, monkeypa
     pos = np.arange(w + h, dtype=np.int32)
     ref, rp, rv = m.copy(), pos.copy(), pos.copy()
     est, eres, epiv, _ = oracle.simplex(ref, w, h, rp, rv, max_pivots=5000, check_cycles=check)
-    for tag, name in (("1", "resident_kernel<256,1,4,tag>"), ("0", "resident_kernel<256,1,4>")):
+    for tag, gen, name in (("1", "2", "resident_kernel<256,1,4,tag>"), ("0", "1", "resident_kernel<256,1,4>"),
+                           ("0", "2", "resident2_kernel<256,1,4>")):  # (gen 2: the second-generation pivot loop, resident2_kernel.cuh)
         monkeypatch.setenv("YALPS_HIP_TAG", tag)
+        monkeypatch.setenv("YALPS_HIP_RESIDENT_GEN", gen)
         c = nat.Context(0)
         t = nat.DeviceTableau(c, w, h)
         try:
@@ -789,6 +799,7 @@ def test_golden_cases_through_the_inplace_kernel(nat, oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("path,env", [("small", {}), ("resident", {"YALPS_HIP_SMALL": "0"}),
+                                      ("resident", {"YALPS_HIP_SMALL": "0", "YALPS_HIP_TAG": "0"}),  # resident2_kernel for the narrow ones too
                                       ("inplace", {"YALPS_HIP_SMALL": "0", "YALPS_HIP_RESIDENT": "0"}),
                                       ("streaming", {"YALPS_HIP_SMALL": "0", "YALPS_HIP_RESIDENT": "0", "YALPS_HIP_INPLACE": "0"})])
 def test_degenerate_integer_lps_on_every_path(nat, oracle, monkeypatch, path, env):

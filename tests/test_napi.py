@@ -128,3 +128,75 @@ def test_addon_solve_integer(name, node_batch):
     assert got["status"] == ref["status"] and (got["result"] == ref["result"] or (got["result"] != got["result"] and ref["result"] != ref["result"]))
     assert got["variables"] == ref["variables"]
     assert K.valid_solution_and_status(got, case["expected"], case["model"], case["options"])
+
+
+SOLVE_CASES = ["Wiki 1", "Stigler Diet", "Monster Problem", "Infeasible 2", "Cycling Introductory Example", "Chvatal Cycling",
+               "Knapsack 1", "Large Farm MIP", "Integer Sports Complex Problem", "Sudoku 4x4", "Monster 2"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SOLVE_CASES)
+def test_node_solve_returns_the_reference_solution(name):
+    """yalps.js `solve(model, options)` under node -- model -> tableau on the JS host, simplex / branch and cut in the addon,
+    Solution marshalled as src/YALPS.ts:8-50 does -- against the Python mirror of the same entry point and the reference
+    test-suite's expected result for the model (status, objective, feasibility)."""
+    from tests import _cases as K
+    from yalps_amd import solve as S
+    case = K.load(name)
+    enc = lambda x: str(x) if isinstance(x, float) and (x != x or x in (float("inf"), float("-inf"))) else x
+    job = {"model": case["model"], "options": {k: enc(v) for k, v in case["options"].items()}}
+    from yalps_amd import build
+    build.build_hip()
+    assert build.build_napi() is not None
+    out = subprocess.run(["node", os.path.join(ROOT, "yalps_amd", "napi", "run_solve.js")], input=json.dumps(job),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert "error" not in res, res
+    num = lambda x: float(x) if isinstance(x, str) else x
+    got = {"status": res["status"], "result": num(res["result"]), "variables": [(k, num(v)) for k, v in res["variables"]]}
+    ref = S.solve(case["model"], case["options"])
+    assert got["status"] == ref["status"]
+    assert got["result"] == ref["result"] or (got["result"] != got["result"] and ref["result"] != ref["result"])
+    assert got["variables"] == ref["variables"]
+    assert K.valid_solution_and_status(got, case["expected"], case["model"], case["options"])
+
+
+@pytest.mark.gpu
+def test_node_solve_readme_example():
+    """README.md:63-79 of the reference through yalps.js (needs the GPU: skipped without one)."""
+    from yalps_amd import _native
+    if _native.lib().yalps_device_count() == 0:
+        pytest.skip("no GPU")
+    model = {"direction": "maximize", "objective": "profit",
+             "constraints": {"wood": {"max": 300}, "labor": {"max": 110}, "storage": {"max": 400}},
+             "variables": {"table": {"wood": 30, "labor": 5, "profit": 1200, "storage": 30},
+                           "dresser": {"wood": 20, "labor": 10, "profit": 1600, "storage": 50}},
+             "integers": ["table", "dresser"]}
+    out = subprocess.run(["node", os.path.join(ROOT, "yalps_amd", "napi", "run_solve.js")], input=json.dumps({"model": model}),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert json.loads(out.stdout.strip().splitlines()[-1]) == {"status": "optimal", "result": 14400, "variables": [["table", 8], ["dresser", 3]]}
+
+
+def test_js_tableau_model_builds_the_reference_tableaux():
+    """yalps.js's model -> tableau conversion (CPU only: the addon is stubbed out) on all 46 models of the reference
+    test-suite: width, height, sign, integer columns and the matrix bytes equal the Python mirror's, which
+    tests/test_host_model.py pins to the tableaux the reference's own tableauModel built (tests/golden)."""
+    from tests import _cases as K
+    from yalps_amd import model as M
+    js = ("const path=require('path'), Module=require('module'); const orig=Module._load;"
+          "Module._load=function(req,...a){ if(req.endsWith('yalps_napi.node')) return {}; return orig.call(this,req,...a)};"
+          "const y=require(path.resolve('yalps_amd/napi/yalps.js'));"
+          "const cases=JSON.parse(require('fs').readFileSync(0,'utf-8'));"
+          "console.log(JSON.stringify(cases.map(c=>{const t=y.tableauModel(c,0); return {w:t.width,h:t.height,sign:t.sign,"
+          "ints:t.integers,m:Buffer.from(t.matrix.buffer).toString('hex')}})));")
+    names = K.names()
+    models = [K.load(n)["model"] for n in names]
+    out = subprocess.run(["node", "-e", js], input=json.dumps(models), capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert out.returncode == 0, out.stderr
+    for name, mdl, r in zip(names, models, json.loads(out.stdout)):
+        tm = M.tableau_model(mdl)
+        m = np.frombuffer(bytes.fromhex(r["m"]), np.float64)
+        assert (r["w"], r["h"], r["sign"], r["ints"]) == (tm.tableau.width, tm.tableau.height, tm.sign, tm.integers), name
+        assert np.array_equal(m.view(np.int64), tm.tableau.matrix.view(np.int64)), name

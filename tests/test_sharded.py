@@ -69,3 +69,71 @@ def test_sharded_hip_steps(oracle, tmp_path, world, M, N, seed):
     the transport differs."""
     res = run_world("hip", world, M, N, seed, tmp_path)
     check_against_oracle(oracle, res, M, N, seed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,M,N,seed", [(2, 300, 280, 5), (3, 64, 64, 9)])
+def test_sharded_native_loop_host_transport(oracle, tmp_path, world, M, N, seed):
+    """yalps_shard_run -- select, exchange, apply and the status polls all inside the library -- with `world` processes
+    sharing the test GPU; the exchange is the library's host transport (a callback) carried by gloo.  An odd pivot
+    budget is not a multiple of the batch: the loop must stop exactly where the oracle does."""
+    res = run_world("hip-native", world, M, N, seed, tmp_path)
+    check_against_oracle(oracle, res, M, N, seed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,seed", [(200, 150, 4), (520, 1100, 3)])
+def test_sharded_native_loop_rccl_one_rank(oracle, tmp_path, M, N, seed):
+    """The native loop over RCCL itself: ncclCommInitRank (one rank), ncclAllGather on the context's stream between the
+    select and the apply kernel, every pivot enqueued by the library's own loop (one hipGraph replay per batch where the
+    runtime lets RCCL be captured) -- bit for bit the oracle.  In a child process that imports torch first, like every
+    multi-rank launch does.  (More than one rank per GPU is something RCCL refuses; the multi-rank control flow is covered
+    above and on CPU.)"""
+    out_npz = str(tmp_path / "rccl1.npz")
+    code = (
+        "import sys, json, numpy as np; sys.path.insert(0, %r)\n"
+        "import torch\n"
+        "from tests import _oracle\n"
+        "from yalps_amd import sharded\n"
+        "M, N, seed = %d, %d, %d; w, h = N + 1, M + 1\n"
+        "m = _oracle.load().dense_lp(M, N, seed)\n"
+        "if seed %% 2: m.reshape(h, w)[1::3, 0] *= -0.05\n"
+        "ident = np.arange(w + h, dtype=np.int32); bounds = sharded.partition(h, 1)\n"
+        "ops = sharded.HipShardOps(sharded.local_rows(m, w, h, bounds, 0), w, bounds, 0, h, ident, ident.copy(), device=0)\n"
+        "comm = sharded.native_comm(ops.ctx, 0, 1, transport='rccl')\n"
+        "status, result, pivots = sharded.sharded_simplex_native(ops, comm, max_pivots=float('inf'), check_every=16)\n"
+        "info = comm.info(); lm, pos, var = ops.download(); comm.close(); ops.close()\n"
+        "assert info['transport'] == 'rccl' and int(info['collectives']) >= pivots, info\n"
+        "np.savez(%r, matrix=lm, pos=pos, var=var, status=status, result=result, pivots=pivots)\n"
+        "print('info', json.dumps(info)); print('ok')\n" % (ROOT, M, N, seed, out_npz))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+    check_against_oracle(oracle, np.load(out_npz), M, N, seed)
+
+
+@pytest.mark.gpu
+def test_sharded_python_driver_over_torch_nccl_backend(oracle, tmp_path):
+    """torch.distributed's "nccl" backend (= RCCL) carrying the Python driver's all-gather on device tensors: a group
+    of one rank still initialises RCCL, runs all_gather_into_tensor on torch's stream and orders it against the select
+    and apply kernels enqueued on the same stream through yalps_ctx_create_on_stream."""
+    code = (
+        "import os, sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import torch, torch.distributed as dist\n"
+        "from tests import _oracle\n"
+        "from yalps_amd import sharded\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
+        "M, N, seed = 200, 150, 4; w, h = N + 1, M + 1\n"
+        "m = _oracle.load().dense_lp(M, N, seed); ident = np.arange(w + h, dtype=np.int32)\n"
+        "bounds = sharded.partition(h, 1)\n"
+        "ops = sharded.HipShardOps(sharded.local_rows(m, w, h, bounds, 0), w, bounds, 0, h, ident, ident.copy(), device=0)\n"
+        "comm = sharded.TorchComm(always_collective=True); assert not comm.stage\n"
+        "status, result, pivots = sharded.sharded_simplex(ops, comm, max_pivots=float('inf'), check_every=8)\n"
+        "lm, pos, var = ops.download(); ops.close()\n"
+        "np.savez(%r, matrix=lm, pos=pos, var=var, status=status, result=result, pivots=pivots)\n"
+        "dist.destroy_process_group(); print('ok')\n" % (ROOT, str(tmp_path / "nccl1.npz")))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+    check_against_oracle(oracle, np.load(str(tmp_path / "nccl1.npz")), 200, 150, 4)

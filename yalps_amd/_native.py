@@ -23,12 +23,17 @@ SYMBOLS = (
     "yalps_round_to_precision", "yalps_ctx_create_on_stream", "yalps_tableau_set_shard", "yalps_shard_slot_doubles",
     "yalps_shard_begin", "yalps_shard_select", "yalps_shard_apply", "yalps_shard_poll", "yalps_tableau_info",
     "yalps_tableau_assemble", "yalps_simplex_sparse_f64", "yalps_tableau_apply_cuts", "yalps_tableau_download_solution", "yalps_milp_f64", "yalps_batch_create", "yalps_batch_destroy", "yalps_batch_set_root", "yalps_batch_solve", "yalps_batch_download",
-    "yalps_tableau_debug_stamps",
+    "yalps_tableau_debug_stamps", "yalps_comm_unique_id", "yalps_comm_create", "yalps_comm_create_host", "yalps_comm_destroy",
+    "yalps_comm_info", "yalps_shard_run",
 )
 
 
 class NativeError(RuntimeError):
     pass
+
+
+# int32_t (*yalps_allgather_fn)(void *user, const double *send_host, double *recv_host, int64_t doubles_per_rank)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64)
 
 
 _lib = None
@@ -78,6 +83,19 @@ def lib():
         L.yalps_shard_apply.argtypes = [vp, vp]
         L.yalps_shard_poll.restype = C.c_int32
         L.yalps_shard_poll.argtypes = [vp, C.POINTER(C.c_int32), f64p, C.POINTER(C.c_int64)]
+        L.yalps_comm_unique_id.restype = C.c_int32
+        L.yalps_comm_unique_id.argtypes = [vp]
+        L.yalps_comm_create.restype = C.c_int32
+        L.yalps_comm_create.argtypes = [vp, vp, C.c_int32, C.c_int32, C.POINTER(vp)]
+        L.yalps_comm_create_host.restype = C.c_int32
+        L.yalps_comm_create_host.argtypes = [vp, ALLGATHER_FN, vp, C.c_int32, C.c_int32, C.POINTER(vp)]
+        L.yalps_comm_destroy.restype = None
+        L.yalps_comm_destroy.argtypes = [vp]
+        L.yalps_comm_info.restype = C.c_int32
+        L.yalps_comm_info.argtypes = [vp, C.c_char_p, C.c_int32]
+        L.yalps_shard_run.restype = C.c_int32
+        L.yalps_shard_run.argtypes = [vp, vp, C.c_double, C.c_double, C.c_int32, C.POINTER(C.c_int32), f64p,
+                                      C.POINTER(C.c_int64), C.POINTER(C.c_float)]
         L.yalps_batch_create.restype = C.c_int32
         L.yalps_batch_create.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
         L.yalps_batch_destroy.restype = None
@@ -298,6 +316,14 @@ class DeviceTableau:
     def shard_apply(self, gathered_ptr):
         check(lib().yalps_shard_apply(self.handle, C.c_void_p(gathered_ptr)))
 
+    def shard_run(self, comm, precision=1e-8, max_pivots=8192.0, check_every=64):
+        """The whole row-sharded solve natively (yalps_shard_run): no Python between two pivots.
+        Returns (status code, result, n_pivots, gpu_ms)."""
+        st, res, npiv, ms = C.c_int32(), C.c_double(), C.c_int64(), C.c_float()
+        check(lib().yalps_shard_run(self.handle, comm.handle, precision, float(max_pivots), int(check_every), C.byref(st),
+                                    C.byref(res), C.byref(npiv), C.byref(ms)))
+        return st.value, res.value, npiv.value, ms.value
+
     def shard_poll(self):
         st, res, npiv = C.c_int32(), C.c_double(), C.c_int64()
         check(lib().yalps_shard_poll(self.handle, C.byref(st), C.byref(res), C.byref(npiv)))
@@ -306,6 +332,53 @@ class DeviceTableau:
     def close(self):
         if self.handle:
             lib().yalps_tableau_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+
+class Comm:
+    """This rank's end of the sharded solve's exchange (yalps_comm): RCCL, or a host all-gather callback."""
+
+    def __init__(self, handle, keep=None):
+        self.handle, self._keep = handle, keep
+
+    @staticmethod
+    def unique_id():
+        """128 bytes from ncclGetUniqueId: made on rank 0, handed to every rank by the host's own channel."""
+        buf = C.create_string_buffer(128)
+        check(lib().yalps_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def rccl(cls, ctx, unique_id, rank, nranks):
+        h = C.c_void_p()
+        check(lib().yalps_comm_create(ctx.handle, C.c_char_p(bytes(unique_id)), rank, nranks, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def host(cls, ctx, allgather, rank, nranks):
+        """allgather(send: float64[n]) -> float64[nranks * n] on host arrays (e.g. a gloo all-gather)."""
+        def thunk(_user, send, recv, n):
+            try:
+                out = allgather(np.ctypeslib.as_array(send, shape=(n,)).copy())
+                np.ctypeslib.as_array(recv, shape=(nranks * n,))[:] = out
+                return 0
+            except Exception:  # (never unwind through the C frames)
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb = ALLGATHER_FN(thunk)
+        h = C.c_void_p()
+        check(lib().yalps_comm_create_host(ctx.handle, cb, None, rank, nranks, C.byref(h)))
+        return cls(h, keep=cb)
+
+    def info(self):
+        buf = C.create_string_buffer(256)
+        check(lib().yalps_comm_info(self.handle, buf, 256))
+        return dict(kv.split("=", 1) for kv in buf.value.decode().split(" ") if "=" in kv)
+
+    def close(self):
+        if self.handle:
+            lib().yalps_comm_destroy(self.handle)
             self.handle = C.c_void_p()
 
 

@@ -74,17 +74,17 @@ def kernel_metadata(lib=LIB):
 # Kernels whose rows / tableaux live in registers or LDS behind hand-written sc1 loads and stores: built without
 # scratch and without accumulator registers, or not at all.  (Two instantiations that broke this rule computed wrong
 # rows on the GPU -- DESIGN.md 4.7 -- so the rule is part of the build, not of an optional test.)
-NO_SCRATCH = ("small_kernel", "batch_kernel", "assemble", "resident_kernel", "stream_kernel", "sweep_kernel")
+NO_SCRATCH = ("small_kernel", "batch_kernel", "assemble", "resident_kernel", "resident2_kernel", "stream_kernel", "sweep_kernel")
 
 
 def check_register_budgets(lib=LIB, min_resident=15):
     ks = kernel_metadata(lib)
-    resident = {k: v for k, v in ks.items() if "resident_kernel" in k}
+    resident = {k: v for k, v in ks.items() if "resident_kernel" in k or "resident2_kernel" in k}
     bad = []
     if len(resident) < min_resident:
         bad.append("only %d resident_kernel instantiations in the code object" % len(resident))
     for name, md in sorted(ks.items()):
-        if "resident_kernel" in name and (int(md["vgpr_count"]) > 256 or int(md["agpr_count"]) != 0):
+        if ("resident_kernel" in name or "resident2_kernel" in name) and (int(md["vgpr_count"]) > 256 or int(md["agpr_count"]) != 0):
             bad.append("%s: vgpr_count %s agpr_count %s" % (name, md["vgpr_count"], md["agpr_count"]))
         if any(tag in name for tag in NO_SCRATCH) and int(md["private_segment_fixed_size"]) != 0:
             bad.append("%s: private_segment_fixed_size %s (scratch)" % (name, md["private_segment_fixed_size"]))

@@ -19,11 +19,12 @@ namespace {
 #define RVARIANT(T, J, R) {T, J, R, reinterpret_cast<const void *>(&resident2_kernel<T, J, R>)}
 } // namespace
 PersistentTable yalps_resident2_table_a() { // (the shapes of yalps_resident_table_a)
+    // Only the shapes hipcc builds within the register budget: the scalar control flow of the second generation costs
+    // more live registers; the others (taller / wider per workgroup) spill and stay on resident_kernel.
     static const PersistentEntry kEntries[] = {
-    RVARIANT(256, 1, 4), RVARIANT(256, 1, 9), RVARIANT(256, 1, 16),
-    RVARIANT(256, 2, 4), RVARIANT(256, 2, 9),
-    RVARIANT(512, 1, 24), RVARIANT(512, 1, 32), RVARIANT(512, 1, 40),
-    RVARIANT(512, 2, 4), RVARIANT(512, 2, 6), RVARIANT(512, 2, 9), RVARIANT(512, 2, 12),
+    RVARIANT(256, 1, 4), RVARIANT(256, 1, 9),
+    RVARIANT(256, 2, 4),
+    RVARIANT(512, 2, 4), RVARIANT(512, 2, 6), RVARIANT(512, 2, 9),
 };
     return {kEntries, (int)(sizeof kEntries / sizeof kEntries[0])};
 }

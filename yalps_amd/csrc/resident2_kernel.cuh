@@ -92,9 +92,12 @@ __device__ __forceinline__ KI block_argmin2(KI v, double (*sk)[16], int (*si)[16
     __syncthreads();
     const double k = sk[slot][lane & (NW - 1)]; // every group of NW lanes holds all NW wave results
     const int i = si[slot][lane & (NW - 1)];
+    // (scalar registers: what follows from the result -- row, column, slot, lane tests -- then compiles to scalar branches
+    // instead of v_cmp + exec-mask sequences, which were most of a pivot's instruction stream)
+    const double km = rowN_min_raw<STEPS>(k);
     KI r;
-    r.k = rowN_min_raw<STEPS>(k);
-    r.i = rowN_min<STEPS>(k == r.k ? i : INT_MAX);
+    r.k = uniform_f64(km);
+    r.i = __builtin_amdgcn_readfirstlane(rowN_min<STEPS>(k == km ? i : INT_MAX));
     return r;
 }
 
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(T) void resident2_kernel(Desc d, int parity, int ch
         KI v = {bi == INT_MAX ? INFINITY : -best, bi};
         v = block_argmin2<T>(v, sk, si, slot);
         slot ^= 1;
-        la = v.i == INT_MAX ? 0 : v.i;
+        la = v.i == INT_MAX ? 0 : v.i; // (scalar registers: block_argmin2)
         la_val = -v.k;
     };
     // Look-ahead, step 1: the lane that holds column la deposits my rows' entries of that column (as the registers hold
@@ -207,22 +210,18 @@ __global__ __launch_bounds__(T) void resident2_kernel(Desc d, int parity, int ch
     auto deposit_la = [&](const double2 (&pvn)[J], unsigned nzmask, bool pending) __attribute__((always_inline)) {
         const int ula = (la - 1) >> 1, ela = (la - 1) & 1, lt = ula % T, lj = ula / T;
         if (la > 0 && wave == (lt >> 6)) { // (uniform)
-            if (tid == lt) {
 #pragma unroll
-                for (int j = 0; j < J; j++) {
-                    if (j != lj) continue; // (uniform)
-                    if (ela) {
+            for (int j = 0; j < J; j++)
 #pragma unroll
-                        for (int g = 0; g < R; g++) sh_raw[g] = x[g][j].y;
-                        if (pending) sh_raw[R] = pvn[j].y;
-                    } else {
+                for (int e = 0; e < 2; e++)
+                    if (2 * (tid + j * T) + e + 1 == la) { // (one lane of the workgroup, one (j, e): no register is indexed at run time)
 #pragma unroll
-                        for (int g = 0; g < R; g++) sh_raw[g] = x[g][j].x;
-                        if (pending) sh_raw[R] = pvn[j].x;
+                        for (int g = 0; g < R; g++) sh_raw[g] = e ? x[g][j].y : x[g][j].x;
+                        if (pending) {
+                            sh_raw[R] = e ? pvn[j].y : pvn[j].x;
+                            sh_pnz = (nzmask >> (2 * j + e)) & 1u;
+                        }
                     }
-                    if (pending) sh_pnz = (nzmask >> (2 * j + ela)) & 1u;
-                }
-            }
         }
         __syncthreads();
     };
@@ -307,7 +306,7 @@ __global__ __launch_bounds__(T) void resident2_kernel(Desc d, int parity, int ch
             if (tid < R) value = sh_raw[tid];
         }
         candidate(phase, value, cur); // (no pivot in flight: the next one reads sh_cf[cur])
-        publish_stores(sh_cg);
+        publish_stores(__builtin_amdgcn_readfirstlane(sh_cg));
         publish_flag();
     };
 
@@ -365,6 +364,10 @@ __global__ __launch_bounds__(T) void resident2_kernel(Desc d, int parity, int ch
             continue;
         }
         const int row = c.i, owner = row % NB;
+        if ((unsigned)row >= (unsigned)h) { // (never expected: a record that names no row of this tableau -- leave with the error
+            if (tid == 0) __hip_atomic_store(d.rc_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // word set instead of indexing with it)
+            return;
+        }
         // ---------------- the winner's raw row (sc1 loads only) ----------------------------------
         // (phase 2: the quotient M[row, la] rides along as one more 8-byte load of the same row)
         const double *src = d.rc_rows[par] + (size_t)owner * pitch;
@@ -459,8 +462,12 @@ __global__ __launch_bounds__(T) void resident2_kernel(Desc d, int parity, int ch
         double cf[R]; // uniform: pivot-column entry of each of my rows (phase 2: left there by the last look-ahead)
 #pragma unroll
         for (int g = 0; g < R; g++) // (scalar registers where the VGPR budget of 2 waves per SIMD is short)
-            cf[g] = (T >= 512 && J * R >= 24) ? uniform_f64(sh_cf[cur][g]) : sh_cf[cur][g];
+            cf[g] = (T >= 512 && J * R >= 18) ? uniform_f64(sh_cf[cur][g]) : sh_cf[cur][g];
         const double my_coef = tid < R ? sh_cf[cur][tid] : 0.0;
+        // rows of mine this pivot changes (:31), one bit per slot, in scalar registers
+        const int lane = tid & 63;
+        const double lane_cf = sh_cf[cur][lane < R ? lane : 0];
+        const unsigned long long touched = __builtin_amdgcn_ballot_w64(lane < R && b + NB * lane < h && fabs(lane_cf) > 1e-16);
         // :14-24 normalise; which of my columns were flushed
         unsigned nzmask = 0;
 #pragma unroll
@@ -532,13 +539,14 @@ __global__ __launch_bounds__(T) void resident2_kernel(Desc d, int parity, int ch
         YSTAMP(6);
         // my rows in the slots of `set` (bit g), fully, as pivot() leaves them
         auto finish_rows = [&](unsigned long long set) __attribute__((always_inline)) {
+            const unsigned long long pivbit = lslot >= 0 ? (1ull << lslot) & set : 0ull; // the pivot row, if it is mine and in the set
+            const unsigned long long elim = set & touched & ~pivbit;                      // rows to eliminate (:31)
 #pragma unroll
-            for (int g = 0; g < R; g++) { // (g must stay a compile-time index: the rows are registers)
-                if (!((set >> g) & 1u)) continue; // (uniform)
-                if (g == lslot) {
+            for (int g = 0; g < R; g++) { // (g must stay a compile-time index: the rows are registers; every test is scalar)
+                if ((pivbit >> g) & 1u) {
 #pragma unroll
                     for (int j = 0; j < J; j++) x[g][j] = pv[j];
-                } else if (b + NB * g < h && fabs(cf[g]) > 1e-16) { // :31 (uniform per row)
+                } else if ((elim >> g) & 1u) {
                     if (fast) {
 #pragma unroll
                         for (int j = 0; j < J; j++) {
@@ -557,13 +565,12 @@ __global__ __launch_bounds__(T) void resident2_kernel(Desc d, int parity, int ch
                     }
                 }
             }
-            if (wave == col_wave) { // the pivot column itself (:25, :36): patched by the one lane that holds it
+            if (wave == col_wave && (elim | pivbit) != 0) { // the pivot column itself (:25, :36): patched by the one lane that holds it
                 if (tid == col_tid) {
 #pragma unroll
                     for (int g = 0; g < R; g++) {
-                        if (!((set >> g) & 1u)) continue;
-                        if (g != lslot && !(b + NB * g < h && fabs(cf[g]) > 1e-16)) continue;
-                        const double v = sh_nq[g == lslot ? R + 1 : g];
+                        if (!(((elim | pivbit) >> g) & 1u)) continue;
+                        const double v = sh_nq[((pivbit >> g) & 1u) ? R + 1 : g];
 #pragma unroll
                         for (int j = 0; j < J; j++)
                             if (j == col_j) {
@@ -600,7 +607,7 @@ __global__ __launch_bounds__(T) void resident2_kernel(Desc d, int parity, int ch
             }
             candidate(phase, value, cur ^ 1);
             YSTAMP(8);
-            const int cg = sh_cg;
+            const int cg = __builtin_amdgcn_readfirstlane(sh_cg);
             finish_rows(ONE << cg);
             YSTAMP(9);
             publish_stores(cg);

@@ -448,6 +448,10 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
             continue;
         }
         const int row = c.i, owner = row % NB;
+        if ((unsigned)row >= (unsigned)h) { // (never expected: a record that names no row of this tableau -- leave with the error
+            if (tid == 0) __hip_atomic_store(d.rc_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // word set instead of indexing with it)
+            return;
+        }
         // ---------------- the winner's raw row (sc1 loads only) ----------------------------------
         double rhs_row;
         double2 pv[J];

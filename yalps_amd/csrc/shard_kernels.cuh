@@ -12,6 +12,9 @@
 //   [8 .. 8+pitch) raw ratio-candidate row   [8+pitch .. 8+2*pitch) raw rhs-candidate row
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void shard_select_kernel(Desc d, int parity, double *send) {
+    // Grid of gridDim.x workgroups: every one reduces the (<= 1024) partials for itself -- identical inputs, identical
+    // result -- and copies its slice of the two candidate rows, 16 bytes per lane (was: one workgroup, 8 bytes per lane:
+    // 2 x 131 KB at w = 16385 took longer than the all-gather it feeds).
     __shared__ double sk[2][16];
     __shared__ int si[2][16];
     const YState *S = d.st + parity;
@@ -29,7 +32,7 @@ __global__ __launch_bounds__(1024) void shard_select_kernel(Desc d, int parity, 
     cn = block_argmin<1024>(cn, sk, si, 1);
     const double *mat = d.mat[S->mbuf], *rhs = d.rhs[S->mbuf];
     const int lr = cr.i == INT_MAX ? 0 : cr.i - d.row_base, ln = cn.i == INT_MAX ? 0 : cn.i - d.row_base;
-    if (tid == 0) {
+    if (blockIdx.x == 0 && tid == 0) {
         send[0] = cr.k;
         send[1] = (double)cr.i;
         send[2] = cn.k;
@@ -39,9 +42,14 @@ __global__ __launch_bounds__(1024) void shard_select_kernel(Desc d, int parity, 
         send[6] = 0.0;
         send[7] = 0.0;
     }
-    for (int c = tid; c < pitch; c += 1024) {
-        send[SHARD_HDR + c] = mat[(size_t)lr * pitch + c];
-        send[SHARD_HDR + pitch + c] = mat[(size_t)ln * pitch + c];
+    const int units = pitch / 2; // (pitch is a multiple of 16 doubles, SHARD_HDR of 2: every access below is 16-byte aligned)
+    const double2 *r0 = reinterpret_cast<const double2 *>(mat + (size_t)lr * pitch), *r1 = reinterpret_cast<const double2 *>(mat + (size_t)ln * pitch);
+    double2 *o0 = reinterpret_cast<double2 *>(send + SHARD_HDR), *o1 = reinterpret_cast<double2 *>(send + SHARD_HDR + pitch);
+    for (int u = blockIdx.x * 1024 + tid; u < 2 * units; u += gridDim.x * 1024) {
+        if (u < units)
+            o0[u] = r0[u];
+        else
+            o1[u - units] = r1[u - units];
     }
 }
 

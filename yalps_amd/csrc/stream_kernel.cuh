@@ -218,6 +218,10 @@ __global__ __launch_bounds__(T) void stream_kernel(Desc d, int parity, int chunk
             continue;
         }
         const int row = c.i, owner = row % NB;
+        if ((unsigned)row >= (unsigned)h) { // (never expected: a record that names no row of this tableau -- leave with the error
+            if (tid == 0) __hip_atomic_store(d.rc_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // word set instead of indexing with it)
+            return;
+        }
         const int lslot = owner == b ? row / NB : -1; // my slot of the pivot row, if I own it
         // ---------------- the winner's raw row (sc1 loads only) ----------------------------------
         const double *src = d.rc_rows[par] + (size_t)owner * pitch;

@@ -27,6 +27,7 @@
 // first-wins comparisons in every scan.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/file.h>
 #include <sys/stat.h>
@@ -120,6 +121,10 @@ constexpr int XROWS = YALPS_RESIDENT_LDS_MAX_ROWS;
 const std::vector<RVariant> kStream = variants_of({yalps_stream_table()});
 const std::vector<RVariant> kStreamCheck = variants_of({yalps_stream_check_table()});
 constexpr int RESIDENT_CHUNK = 4096; // pivots per launch of the resident kernel (bounds its run time)
+
+struct YalpsNcclId { // ncclUniqueId (rccl.h: 128 opaque bytes, passed by value)
+    char internal[128];
+};
 
 thread_local std::string g_err;
 
@@ -707,7 +712,7 @@ int32_t yalps_tableau_info(const yalps_tableau *t, char *buf, int32_t len) {
     if (!t || !buf || len < 1) return fail(YALPS_E_ARG, "yalps_tableau_info: bad argument");
     char res[96] = "none", inp[64] = "none";
     if (t->rvar.fn)
-        std::snprintf(res, sizeof res, "resident%s_kernel<%d,%d,%d%s> chunk=%d lds_rows=%d", t->rgen == 2 ? "2" : "", t->rvar.T, t->rvar.J, t->rvar.R,
+        std::snprintf(res, sizeof res, "resident%s_kernel<%d,%d,%d%s> chunk=%d lds_rows=%d", t->rgen == 2 && !t->rvar_tag.fn ? "2" : "", t->rvar.T, t->rvar.J, t->rvar.R,
                       t->d.extra ? ",lds" : t->rvar_tag.fn ? ",tag" : "", RESIDENT_CHUNK, t->d.extra);
     if (t->svar.fn) std::snprintf(inp, sizeof inp, "stream_kernel<%d,%d>", t->svar.T, t->svar.J);
     char str[64];
@@ -1440,9 +1445,14 @@ int32_t yalps_shard_begin(yalps_tableau *t, double precision, double maxPivots) 
     return 0;
 }
 
+static int shard_select_blocks(const yalps_tableau *t) { // 16-byte units of the two candidate rows over 1024-lane workgroups
+    const int blocks = (t->d.pitch + 1023) / 1024;
+    return blocks < 1 ? 1 : blocks > 64 ? 64 : blocks;
+}
+
 int32_t yalps_shard_select(yalps_tableau *t, double *send_dev) {
     if (!t || !send_dev) return fail(YALPS_E_ARG, "yalps_shard_select: bad argument");
-    shard_select_kernel<<<dim3(1), dim3(1024), 0, t->ctx->stream>>>(t->d, t->shard_parity, send_dev);
+    shard_select_kernel<<<dim3(shard_select_blocks(t)), dim3(1024), 0, t->ctx->stream>>>(t->d, t->shard_parity, send_dev);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1465,6 +1475,270 @@ int32_t yalps_shard_poll(yalps_tableau *t, int32_t *status_out, double *result_o
     if (status_out) *status_out = now.status;
     if (result_out) *result_out = now.result;
     if (pivots_out) *pivots_out = now.pivots;
+    return 0;
+}
+
+// ---- the exchange of the row-sharded solve, natively: RCCL over xGMI --------------------------------------------
+// RCCL is looked up at run time (dlopen; a copy the process already holds -- torch's -- is reused: both carry the
+// soname librccl.so.1), so the library has no link-time dependency on it and single-GPU users never load it.
+namespace {
+struct Rccl {
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, YalpsNcclId, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::string why;
+};
+Rccl *rccl_load() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names)
+            if ((r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break; // (already in the process?)
+        if (!r.lib)
+            for (const char *n : names)
+                if ((r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!r.lib) {
+            r.why = std::string("librccl.so.1 not found: ") + dlerror();
+            return;
+        }
+        auto sym = [&](const char *n) {
+            void *p = dlsym(r.lib, n);
+            if (!p && r.why.empty()) r.why = std::string("librccl lacks ") + n;
+            return p;
+        };
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+        r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    });
+    return &r;
+}
+#define rccl() (*rccl_load())
+constexpr int NCCL_FLOAT64 = 8, NCCL_UINT64 = 5, NCCL_SUM = 0; // rccl.h: ncclDataType_t / ncclRedOp_t
+#define NCCL_TRY(expr)                                                                                          \
+    do {                                                                                                        \
+        const int e_ = (expr);                                                                                  \
+        if (e_ != 0) return fail(YALPS_E_DEVICE, std::string(#expr) + ": " + (rccl().GetErrorString ? rccl().GetErrorString(e_) : "?")); \
+    } while (0)
+} // namespace
+
+struct yalps_comm {
+    yalps_ctx *ctx = nullptr;
+    int rank = 0, nranks = 1;
+    void *nccl = nullptr;              // ncclComm_t (RCCL transport)
+    yalps_allgather_fn host_fn = nullptr; // host transport (tests / hosts with their own channel): staged through pinned memory
+    void *host_user = nullptr;
+    double *send = nullptr, *recv = nullptr; // device slots: mine, everybody's
+    double *pin = nullptr;                   // pinned staging of the host transport: send slot | gathered slots
+    size_t slot_cap = 0;                     // doubles per slot the buffers hold
+    hipGraphExec_t graph_exec = nullptr;     // one batch of pivots (select, all-gather, apply), captured once per tableau
+    hipGraph_t graph = nullptr;
+    const yalps_tableau *graph_for = nullptr;
+    int graph_steps = 0;
+    bool graph_failed = false;
+    int64_t collectives = 0, graph_replays = 0;
+};
+
+int32_t yalps_comm_unique_id(void *id128) {
+    if (!id128) return fail(YALPS_E_ARG, "yalps_comm_unique_id: NULL argument");
+    Rccl &r = rccl();
+    if (!r.lib || !r.why.empty()) return fail(YALPS_E_DEVICE, "RCCL is not usable: " + r.why);
+    NCCL_TRY(r.GetUniqueId(id128));
+    return 0;
+}
+
+static void comm_free(yalps_comm *c) {
+    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+    if (c->graph) (void)hipGraphDestroy(c->graph);
+    if (c->send) (void)hipFree(c->send);
+    if (c->recv) (void)hipFree(c->recv);
+    if (c->pin) (void)hipHostFree(c->pin);
+    if (c->nccl && rccl().CommDestroy) (void)rccl().CommDestroy(c->nccl);
+    delete c;
+}
+
+int32_t yalps_comm_create(yalps_ctx *ctx, const void *id128, int32_t rank, int32_t nranks, yalps_comm **out) {
+    if (!ctx || !id128 || !out || nranks < 1 || nranks > MAX_SHARDS || rank < 0 || rank >= nranks)
+        return fail(YALPS_E_ARG, "yalps_comm_create: bad argument");
+    *out = nullptr;
+    Rccl &r = rccl();
+    if (!r.lib || !r.why.empty()) return fail(YALPS_E_DEVICE, "RCCL is not usable: " + r.why);
+    HIP_TRY(hipSetDevice(ctx->device));
+    yalps_comm *c = new yalps_comm();
+    c->ctx = ctx;
+    c->rank = rank;
+    c->nranks = nranks;
+    YalpsNcclId id;
+    std::memcpy(&id, id128, sizeof id);
+    const int e = r.CommInitRank(&c->nccl, nranks, id, rank);
+    if (e != 0) {
+        comm_free(c);
+        return fail(YALPS_E_DEVICE, std::string("ncclCommInitRank: ") + (r.GetErrorString ? r.GetErrorString(e) : "?"));
+    }
+    *out = c;
+    return 0;
+}
+
+int32_t yalps_comm_create_host(yalps_ctx *ctx, yalps_allgather_fn fn, void *user, int32_t rank, int32_t nranks, yalps_comm **out) {
+    if (!ctx || !fn || !out || nranks < 1 || nranks > MAX_SHARDS || rank < 0 || rank >= nranks)
+        return fail(YALPS_E_ARG, "yalps_comm_create_host: bad argument");
+    yalps_comm *c = new yalps_comm();
+    c->ctx = ctx;
+    c->rank = rank;
+    c->nranks = nranks;
+    c->host_fn = fn;
+    c->host_user = user;
+    *out = c;
+    return 0;
+}
+
+void yalps_comm_destroy(yalps_comm *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->ctx->device);
+    (void)hipStreamSynchronize(c->ctx->stream);
+    comm_free(c);
+}
+
+static int comm_reserve(yalps_comm *c, size_t slot) {
+    if (slot <= c->slot_cap) return 0;
+    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec); // (the captured batch holds the old addresses)
+    if (c->graph) (void)hipGraphDestroy(c->graph);
+    c->graph_exec = nullptr;
+    c->graph = nullptr;
+    c->graph_for = nullptr;
+    if (c->send) HIP_TRY(hipFree(c->send));
+    if (c->recv) HIP_TRY(hipFree(c->recv));
+    if (c->pin) HIP_TRY(hipHostFree(c->pin));
+    c->send = c->recv = c->pin = nullptr;
+    c->slot_cap = 0;
+    HIP_TRY(hipMalloc(&c->send, sizeof(double) * slot));
+    HIP_TRY(hipMalloc(&c->recv, sizeof(double) * slot * (size_t)c->nranks));
+    HIP_TRY(hipMemset(c->send, 0, sizeof(double) * slot));
+    HIP_TRY(hipMemset(c->recv, 0, sizeof(double) * slot * (size_t)c->nranks));
+    if (c->host_fn) HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->pin), sizeof(double) * slot * ((size_t)c->nranks + 1), hipHostMallocDefault));
+    c->slot_cap = slot;
+    return 0;
+}
+
+// one pivot of the sharded solve on the context's stream: my candidates, the exchange, the elimination
+static int shard_step(yalps_tableau *t, yalps_comm *c, size_t slot) {
+    hipStream_t s = t->ctx->stream;
+    shard_select_kernel<<<dim3(shard_select_blocks(t)), dim3(1024), 0, s>>>(t->d, t->shard_parity, c->send);
+    if (c->nccl) {
+        NCCL_TRY(rccl().AllGather(c->send, c->recv, slot, NCCL_FLOAT64, c->nccl, s));
+    } else { // host transport: down, the host's own all-gather, up (a test / bring-up path: one wait per pivot)
+        HIP_TRY(hipMemcpyAsync(c->pin, c->send, sizeof(double) * slot, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (c->host_fn(c->host_user, c->pin, c->pin + slot, (int64_t)slot) != 0)
+            return fail(YALPS_E_DEVICE, "yalps_shard_run: the host all-gather callback failed");
+        HIP_TRY(hipMemcpyAsync(c->recv, c->pin + slot, sizeof(double) * slot * (size_t)c->nranks, hipMemcpyHostToDevice, s));
+    }
+    c->collectives++;
+    launch_one(t, t->shard_parity, MODE_SHARD, t->ctx->nt_stores ? 64 : 0, c->recv);
+    t->shard_parity ^= 1;
+    return 0;
+}
+
+int32_t yalps_shard_run(yalps_tableau *t, yalps_comm *c, double precision, double maxPivots, int32_t check_every,
+                        int32_t *status_out, double *result_out, int64_t *pivots_out, float *gpu_ms_out) {
+    if (!t || !c || t->height < 1 || t->ctx != c->ctx) return fail(YALPS_E_ARG, "yalps_shard_run: bad argument");
+    if (t->d.nshards != c->nranks || t->d.shard_rank != c->rank)
+        return fail(YALPS_E_ARG, "yalps_shard_run: the tableau's partition (yalps_tableau_set_shard) and the communicator disagree");
+    yalps_ctx *ctx = t->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t slot = (size_t)yalps_shard_slot_doubles(t);
+    if (int rc = comm_reserve(c, slot)) return rc;
+    if (check_every < 2) check_every = 2;
+    check_every &= ~1; // (even: the launch parity is back where it started after a batch, so one captured batch serves every replay)
+    if (int rc = yalps_shard_begin(t, precision, maxPivots)) return rc;
+    if (gpu_ms_out) HIP_TRY(hipEventRecord(ctx->ev0, s));
+    // The first batch runs eagerly (RCCL sets its channels up on first use); from the second on the batch is ONE
+    // hipGraph replay where the transport can be captured (RCCL's collectives can; the host transport waits per pivot).
+    const bool want_graph = c->nccl && !ctx->eager && !c->graph_failed && env_int("YALPS_HIP_SHARD_GRAPH", 1);
+    YState fin;
+    for (int batch = 0;; batch++) {
+        bool replayed = false;
+        if (want_graph && batch >= 1 && !c->graph_failed) {
+            if (!c->graph_exec || c->graph_for != t || c->graph_steps != check_every) {
+                if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+                if (c->graph) (void)hipGraphDestroy(c->graph);
+                c->graph_exec = nullptr;
+                c->graph = nullptr;
+                const int parity0 = t->shard_parity;
+                const int64_t coll0 = c->collectives;
+                std::string why;
+                hipError_t he = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
+                bool ok = he == hipSuccess;
+                if (!ok) why = std::string("hipStreamBeginCapture: ") + hipGetErrorString(he);
+                int rc = 0;
+                if (ok)
+                    for (int i = 0; i < check_every && rc == 0; i++) rc = shard_step(t, c, slot);
+                if (ok && rc != 0) why = "a step failed while being recorded: " + g_err;
+                hipGraph_t g = nullptr;
+                if (ok) {
+                    he = hipStreamEndCapture(s, &g);
+                    if (he != hipSuccess && why.empty()) why = std::string("hipStreamEndCapture: ") + hipGetErrorString(he);
+                    ok = he == hipSuccess && rc == 0 && g != nullptr;
+                }
+                t->shard_parity = parity0; // (nothing ran: capture only recorded)
+                c->collectives = coll0;
+                if (ok) {
+                    he = hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0);
+                    if (he != hipSuccess) why = std::string("hipGraphInstantiate: ") + hipGetErrorString(he);
+                    ok = he == hipSuccess;
+                }
+                if (ok) {
+                    c->graph = g;
+                    c->graph_for = t;
+                    c->graph_steps = check_every;
+                } else {
+                    if (g) (void)hipGraphDestroy(g);
+                    (void)hipGetLastError();
+                    c->graph_failed = true; // (this transport / runtime cannot be captured: enqueue every pivot from here)
+                    std::fprintf(stderr, "yalps_hip: the sharded pivot batch could not be captured into a hipGraph (%s); enqueueing per pivot\n", why.c_str());
+                }
+            }
+            if (c->graph_exec) {
+                HIP_TRY(hipGraphLaunch(c->graph_exec, s));
+                c->collectives += check_every;
+                c->graph_replays++;
+                replayed = true;
+            }
+        }
+        if (!replayed)
+            for (int i = 0; i < check_every; i++)
+                if (int rc = shard_step(t, c, slot)) return rc;
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&t->host_state[1], t->d.st + t->shard_parity, sizeof(YState), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        fin = t->host_state[1];
+        if (fin.status != RUNNING) break;
+    }
+    if (gpu_ms_out) {
+        HIP_TRY(hipEventRecord(ctx->ev1, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipEventElapsedTime(gpu_ms_out, ctx->ev0, ctx->ev1));
+    }
+    t->cur = fin.mbuf;
+    if (status_out) *status_out = fin.status;
+    if (result_out) *result_out = fin.result;
+    if (pivots_out) *pivots_out = fin.pivots;
+    return 0;
+}
+
+int32_t yalps_comm_info(const yalps_comm *c, char *buf, int32_t len) {
+    if (!c || !buf || len < 1) return fail(YALPS_E_ARG, "yalps_comm_info: bad argument");
+    std::snprintf(buf, (size_t)len, "transport=%s rank=%d nranks=%d collectives=%lld graph_replays=%lld graph=%s", c->nccl ? "rccl" : "host",
+                  c->rank, c->nranks, (long long)c->collectives, (long long)c->graph_replays,
+                  c->graph_exec ? "captured" : c->graph_failed ? "failed" : "none");
     return 0;
 }
 

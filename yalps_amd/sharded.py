@@ -8,10 +8,14 @@ w = 16385), so selection and pivot-row broadcast are one exchange and every rank
 same decision from the same bytes.  xGMI is point-to-point; a 2 MB all-gather per pivot is
 latency-bound and far below the local sweep (537 MB of traffic per GPU per pivot at C5).
 
-The per-rank steps are the library's (`yalps_shard_select`, `yalps_shard_apply`); this module only
-sequences them around the collective and polls the replicated status every `check_every` pivots --
-no host round trip per pivot.  The `ops` / `comm` split exists so that the same driver runs
-with the HIP steps + RCCL on GPUs and with a CPU stand-in + gloo in the multi-process tests.
+Two drivers:
+  * `sharded_simplex_native`: the whole loop inside the library (`yalps_shard_run`): select kernel, ncclAllGather on the
+    context's stream, apply kernel, a batch of pivots captured once into a hipGraph and replayed; Python is entered once
+    per solve.  The communicator is the library's own (`_native.Comm.rccl`; the 128-byte RCCL id travels through
+    torch.distributed or any other channel the host has), or a host callback (`_native.Comm.host`) where RCCL cannot
+    run -- ranks that share one GPU in the tests.
+  * `sharded_simplex`: the same steps sequenced from Python around a torch.distributed collective (`TorchComm`); the
+    `ops` / `comm` split lets the multi-process CPU tests drive it with a numpy stand-in + gloo.
 """
 import numpy as np
 
@@ -70,25 +74,58 @@ class HipShardOps:
         m, pos, var = self.tab.download(perm_len=self.perm_len)
         return m, pos, var
 
+    def run_native(self, comm, precision=1e-8, max_pivots=8192.0, check_every=64):
+        """yalps_shard_run: returns (status name, result, n_pivots, gpu_ms)."""
+        st, result, pivots, ms = self.tab.shard_run(comm, precision, max_pivots, check_every)
+        return STATUS[st], result, pivots, ms
+
     def close(self):
         self.tab.close()
         self.ctx.close()
+
+
+def native_comm(ctx, rank, world, transport="rccl", group=None):
+    """This rank's yalps_comm.  "rccl": ncclCommInitRank inside the library, the unique id broadcast from rank 0 through
+    torch.distributed (any backend).  "host": all-gathers staged through host memory and carried by torch.distributed
+    (gloo) -- for ranks that share a GPU, where RCCL refuses to run."""
+    import torch
+    import torch.distributed as dist
+    if transport == "rccl":
+        box = [_native.Comm.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        return _native.Comm.rccl(ctx, box[0], rank, world)
+
+    def allgather(send):
+        if world == 1:
+            return send
+        out = torch.empty(world * send.size, dtype=torch.float64)
+        dist.all_gather_into_tensor(out, torch.from_numpy(send), group=group)
+        return out.numpy()
+    return _native.Comm.host(ctx, allgather, rank, world)
+
+
+def sharded_simplex_native(ops, comm, precision=1e-8, max_pivots=8192.0, check_every=64):
+    """One row-sharded solve with no Python between two pivots; returns (status, result, n_pivots)."""
+    status, result, pivots, _ = ops.run_native(comm, precision, max_pivots, check_every)
+    return status, result, pivots
 
 
 class TorchComm:
     """All-gather of the candidate slots through torch.distributed.  With a backend that cannot
     move device tensors (gloo on this build) the slots are staged through host memory."""
 
-    def __init__(self, group=None, stage_on_host=None):
+    def __init__(self, group=None, stage_on_host=None, always_collective=False):
         import torch.distributed as dist
         self.dist, self.group = dist, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         if stage_on_host is None:
             stage_on_host = dist.is_initialized() and dist.get_backend(group) != "nccl"
         self.stage = stage_on_host
+        self.always = always_collective and dist.is_initialized()  # (a group of one still goes through the backend)
 
     def all_gather(self, recv, send):
-        if self.world == 1:
+        if self.world == 1 and not self.always:
             recv.copy_(send)
         elif self.stage and recv.is_cuda:
             s = send.cpu()
