@@ -3,6 +3,7 @@ statistics and the table layout, on CPU with stub runners."""
 import math
 
 import numpy as np
+import pytest
 
 from yalps_amd import benchmark as B
 
@@ -50,3 +51,36 @@ def test_benchmark_runs_validation_and_sampling():
         raise SystemExit("validation should have failed")
     except AssertionError:
         pass
+
+
+@pytest.mark.gpu
+def test_harness_with_the_hip_runners_on_readme_problems():
+    """benchmarks/benchmark.ts:98-126 with the MI355X runners on four of the reference README's problems (two MILPs, one
+    LP from the test-suite's data, one netlib LP): every runner's result is validated against the expected optimum first
+    (validate(), relative 1e-5 / the model's tolerance), then sampled; the table has one row per runner, sorted by mean,
+    slowdown 1 for the fastest."""
+    import os
+
+    from tests import _cases as K, _golden as G
+    from yalps_amd import mps, solve as S
+    netlib = {b["name"]: b for b in mps.read_benchmarks(os.path.join(G.GOLDEN, "netlib"))}
+    benches = []
+    for name in ("Monster Problem", "Large Farm MIP", "Knapsack 1", "SC205"):
+        if name in netlib:
+            b = netlib[name]
+            mdl, opt, expected = b["model"], dict(b["options"]), b["expected"]
+        else:
+            c = K.load(name)
+            mdl, opt, expected = c["model"], dict(c["options"]), c["expected"]["result"]
+        benches.append({"name": name, "model": mdl, "options": {**S.default_options, **opt}, "expected": expected})
+    lines = []
+    tables = B.benchmark(benches, B.runners, num_samples=5, out=lines.append)
+    assert len(tables) == 4 and all(len(t) == len(B.runners) for _, t in tables)
+    for head, table in tables:
+        means = [row["mean"] for row in table.values()]
+        assert means == sorted(means) and list(table.values())[0]["slowdown"] == 1.0 and all(m > 0 for m in means), (head, table)
+    assert lines[0].startswith("Monster Problem: 600 constraints, 552 variables, 0 integers")
+    # a runner that returns a wrong optimum must be caught by the validation pass, before anything is timed
+    wrong = B.Runner("wrong", B.hip_runner.convert, B.hip_runner.solve, lambda s: s["result"] * 1.01 + 1.0)
+    with pytest.raises(AssertionError):
+        B.benchmark(benches[:1], [wrong], num_samples=2, out=lines.append)

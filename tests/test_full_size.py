@@ -38,8 +38,8 @@ def reference(negate):
 
 
 def test_c5_streaming_kernel_matches_restatement():
-    """One GPU, phase-2 pivots, the any-shape DECIDE + APPLY pair that unsharded 8194..16385-column tableaux
-    take; the whole 2.1 GB tableau is compared."""
+    """One GPU, phase-2 pivots, sweep_kernel (persistent, in place, non-temporal row traffic) that unsharded
+    8194..16385-column tableaux take; the whole 2.1 GB tableau is compared."""
     c5 = reference(negate=False)
     nat, w, h = c5["nat"], c5["w"], c5["h"]
     ctx = nat.Context(0)
@@ -48,7 +48,7 @@ def test_c5_streaming_kernel_matches_restatement():
         ident = np.arange(w + h, dtype=np.int32)
         t.upload(c5["m"], h, ident, ident.copy())
         status, result, npiv, _ = t.solve(max_pivots=MAX_PIVOTS)
-        assert t.info()["last_path"] == "generic" and t.info()["streaming"] == "wide_kernel<1024,8>"
+        assert t.info()["last_path"] == "inplace" and t.info()["inplace"] == "sweep_kernel<512,16,nt>", t.info()
         got, gpos, gvar = t.download()
     finally:
         t.close()

@@ -844,6 +844,81 @@ def test_degenerate_integer_lps_on_every_path(nat, oracle, monkeypatch, path, en
     assert {"optimal", "unbounded"} <= seen, seen
 
 
+# ---- sweep_kernel: persistent, in place, for what streams from HBM (8194 .. 16385 columns; 4098 .. 8193 beyond the cache) ----
+SWEEP = [  # M, N, pivots, env, expected kernel, checkCycles
+    (600, 16000, 70, {}, "sweep_kernel<512,16>", False),
+    (300, 9000, 60, {"YALPS_HIP_SWEEP_NT": "1"}, "sweep_kernel<512,16,nt>", False),
+    (2100, 12345, 50, {}, "sweep_kernel<512,16>", False),
+    (1400, 8000, 80, {"YALPS_HIP_SWEEP": "2"}, "sweep_kernel<512,8>", False),
+    (2500, 5000, 60, {"YALPS_HIP_SWEEP": "2", "YALPS_HIP_SWEEP_NT": "1"}, "sweep_kernel<512,8,nt>", False),
+    (900, 7000, 60, {"YALPS_HIP_SWEEP": "2"}, "sweep_kernel<512,8>", True),
+]
+
+
+@pytest.mark.parametrize("M,N,pivots,env,kernel,check", SWEEP)
+def test_sweep_kernel_matches_restatement(nat, ctx, monkeypatch, M, N, pivots, env, kernel, check):
+    """sweep_kernel on dense tableaux with a phase-1 start, exact zeros (untouched rows, flushed pivot-row entries: the
+    non-zero-mask path) and -- in one case -- checkCycles: `pivots` pivots against the pinned numpy restatement, every
+    bit of the tableau, the basis and the pivot count; both cache policies, both unit counts (the switches are read when
+    the tableau is created)."""
+    from tests import _np_simplex as NP
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    w, h = N + 1, M + 1
+    m = nat.dense_lp(M, N, 17)
+    A = m.reshape(h, w)
+    A[h // 3] *= -1.0          # "-a x <= -b": phase 1 first
+    A[5::7, 3::5] = 0.0        # exact zeros
+    A[2::9, 0] = 0.0           # degenerate rows (ratio <= precision)
+    pos, var = np.arange(w + h, dtype=np.int32), np.arange(w + h, dtype=np.int32)
+    ref, rpos, rvar = m.copy(), pos.copy(), var.copy()
+    est, eres, epiv = NP.simplex(ref, w, h, rpos, rvar, max_pivots=pivots)
+    t = nat.DeviceTableau(ctx, w, h)
+    try:
+        t.upload(m, h, pos, var)
+        status, result, npiv, _ = t.solve(max_pivots=pivots, check_cycles=check)
+        info = t.info()
+        got, gpos, gvar = t.download()
+    finally:
+        t.close()
+    assert info["last_path"] == "inplace" and info["inplace"] == kernel, info
+    assert (status, npiv) == (est, epiv) and G.same_number(result, eres)
+    assert np.array_equal(gpos, rpos) and np.array_equal(gvar, rvar)
+    assert np.array_equal(got.view(np.int64), ref.view(np.int64))
+
+
+@pytest.mark.parametrize("kind", ["optimal", "unbounded", "infeasible"])
+def test_sweep_kernel_whole_solves(nat, ctx, oracle, kind):
+    """sweep_kernel to the end of a solve (120 x 9001: few, very wide rows): optimal, unbounded (result = the column) and
+    infeasible, against the oracle bit for bit."""
+    M, N = 120, 9000
+    w, h = N + 1, M + 1
+    m = nat.dense_lp(M, N, 23)
+    A = m.reshape(h, w)
+    if kind == "unbounded":
+        A[0, 7] = 0.99
+        A[1:, 7] = -A[1:, 7]
+    elif kind == "infeasible":
+        A[h // 2] = -A[h // 2]
+        A[h // 2, 0] = -1e7
+    pos, var = np.arange(w + h, dtype=np.int32), np.arange(w + h, dtype=np.int32)
+    ref, rpos, rvar = m.copy(), pos.copy(), var.copy()
+    est, eres, epiv, _ = oracle.simplex(ref, w, h, rpos, rvar, max_pivots=np.inf)
+    assert est == kind, (est, epiv)
+    t = nat.DeviceTableau(ctx, w, h)
+    try:
+        t.upload(m, h, pos, var)
+        status, result, npiv, _ = t.solve(max_pivots=np.inf)
+        info = t.info()
+        got, gpos, gvar = t.download()
+    finally:
+        t.close()
+    assert info["last_path"] == "inplace" and info["inplace"].startswith("sweep_kernel<512,16"), info
+    assert (status, npiv) == (est, epiv) and G.same_number(result, eres)
+    assert np.array_equal(gpos, rpos) and np.array_equal(gvar, rvar)
+    assert np.array_equal(got.view(np.int64), ref.view(np.int64))
+
+
 # ---- rows wider than 16385 columns: the any-shape DECIDE + APPLY pair (generic_kernels.cuh) ---------------
 @pytest.mark.parametrize("M,N,pivots,check", [(200, 20000, 90, False), (60, 17000, 5000, False), (400, 33000, 60, True)])
 def test_generic_path_for_very_wide_tableaux(nat, ctx, M, N, pivots, check):

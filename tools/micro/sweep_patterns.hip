@@ -53,6 +53,72 @@ __global__ __launch_bounds__(T) void sweep(double *__restrict__ a, const double 
     }
 }
 
+// the same with the pivot row in LDS instead of registers (what frees 4 J registers per lane for a second row in flight)
+template <int T, int J, int D, bool NT>
+__global__ __launch_bounds__(T) void sweep_lds(double *__restrict__ a, const double *__restrict__ p, const double *__restrict__ coef,
+                                               int rows, int pitch) {
+    extern __shared__ double prow[];
+    const int tid = threadIdx.x, b = blockIdx.x, NB = gridDim.x;
+#pragma unroll
+    for (int j = 0; j < J; j++) *reinterpret_cast<v2 *>(prow + 2 * (tid + j * T)) = *reinterpret_cast<const v2 *>(p + 2 * (tid + j * T));
+    __syncthreads();
+    const int count = b < rows ? (rows - 1 - b) / NB + 1 : 0;
+    for (int i = 0; i < count; i += D) {
+        v2 x[D][J];
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            const int r = b + (i + d < count ? i + d : i) * NB;
+            const double *src = a + (size_t)r * pitch;
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                const v2 *q = reinterpret_cast<const v2 *>(src + 2 * (tid + j * T));
+                x[d][j] = NT ? __builtin_nontemporal_load(q) : *q;
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            if (i + d >= count) break;
+            const int r = b + (i + d) * NB;
+            const double c = coef[r];
+            double *dst = a + (size_t)r * pitch;
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                v2 v = x[d][j];
+                const v2 pr = *reinterpret_cast<const v2 *>(prow + 2 * (tid + j * T));
+                const double px = c * pr.x, py = c * pr.y;
+                v.x = v.x - px;
+                v.y = v.y - py;
+                v2 *q = reinterpret_cast<v2 *>(dst + 2 * (tid + j * T));
+                if (NT)
+                    __builtin_nontemporal_store(v, q);
+                else
+                    *q = v;
+            }
+        }
+    }
+}
+template <int T, int J, int D, bool NT>
+void run_lds(double *a, double *p, double *coef, int rows, int pitch) {
+    if (T * J * 2 != pitch) return;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_lds<T, J, D, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, pitch * 8);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const int reps = 6;
+    for (int i = 0; i < reps + 2; i++) {
+        if (i == 2) hipEventRecord(e0);
+        sweep_lds<T, J, D, NT><<<256, T, pitch * 8>>>(a, p, coef, rows, pitch);
+    }
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double bytes = 2.0 * rows * (double)pitch * 8;
+    printf("%6dx%-6d T=%4d J=%d D=%d %s strided G=1 prow-in-LDS %9.1f us  %.2f TB/s\n", rows, pitch, T, J, D, NT ? "nt   " : "plain", 1e3 * ms / reps,
+           bytes / (ms / reps * 1e-3) / 1e12);
+    fflush(stdout);
+}
+
 template <int T, int J, int D, bool NT, bool BLOCKED>
 void run(const char *name, double *a, double *p, double *coef, int rows, int pitch, int G) {
     if (T * J * 2 != pitch) return;
@@ -94,6 +160,13 @@ int main() {
         run<1024, 8, 2, true, true>("", a, p, coef, rows, pitch, 1);
         run<1024, 8, 1, true, false>("", a, p, coef, rows, pitch, 2);
         run<512, 16, 1, true, false>("", a, p, coef, rows, pitch, 1);
+        run<512, 16, 2, true, false>("", a, p, coef, rows, pitch, 1);
+        run<512, 16, 2, false, false>("", a, p, coef, rows, pitch, 1);
+        run_lds<1024, 8, 2, true>(a, p, coef, rows, pitch);
+        run_lds<1024, 8, 2, false>(a, p, coef, rows, pitch);
+        run_lds<1024, 8, 3, true>(a, p, coef, rows, pitch);
+        run_lds<1024, 4, 2, true>(a, p, coef, rows, pitch);
+        run_lds<1024, 4, 3, true>(a, p, coef, rows, pitch);
         run<512, 16, 1, true, false>("", a, p, coef, rows, pitch, 2);
         run<512, 16, 1, false, false>("", a, p, coef, rows, pitch, 2);
         run<256, 32, 1, true, false>("", a, p, coef, rows, pitch, 4);

@@ -80,6 +80,10 @@ struct Desc {
     int32_t xl_ofs; // ... and where they start in the dynamic LDS block, in int32 units (behind var[] / pos[] at capacity)
     // any-shape fallback (generic_kernels.cuh): the normalised pivot row [pitch] and {quotient, its RHS, RHS non-zero}
     double *gen_prow, *gen_scal;
+    // sweep_kernel (persistent, in place, rows of 8194 .. 16385 columns): its records in the zeroed control block, and
+    // whether the row traffic is non-temporal (tableau beyond the Infinity Cache)
+    unsigned long long *sw_sync, *sw_recs;
+    int32_t sw_nt;
     // diagnostic build only (-DYALPS_STAMPS, never the shipped library): [nb][STAMP_WORDS] per-workgroup stage sums in
     // shader cycles, written once when a persistent launch ends; no kernel reads it
     unsigned long long *dbg;

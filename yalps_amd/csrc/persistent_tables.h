@@ -24,6 +24,10 @@ PersistentTable yalps_resident_lds_table();
 constexpr int YALPS_RESIDENT_LDS_MAX_ROWS = 8;
 // resident_kernel<T, J, R, false, true>: the candidate row travels as self-validating granules (narrow rows)
 PersistentTable yalps_resident_tag_table();
+// sweep_kernel<T, J, false> / <T, J, true>: persistent, in place, for tableaux that stream from HBM (sweep_kernel.cuh)
+PersistentTable yalps_sweep_table();
+PersistentTable yalps_sweep_check_table();
+int yalps_sweep_sync_bytes(); // sizeof(SweepSync): its records at the head of the sweep part of the control block
 // stream_kernel<T, J, false> / <T, J, true> (with hasCycle): persistent, in place
 PersistentTable yalps_stream_table();
 PersistentTable yalps_stream_check_table();

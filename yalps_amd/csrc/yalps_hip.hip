@@ -120,6 +120,11 @@ constexpr int XROWS = YALPS_RESIDENT_LDS_MAX_ROWS;
 // stream_kernel<lanes, 16-byte units per lane and row, hasCycle>: same signature as the resident kernel
 const std::vector<RVariant> kStream = variants_of({yalps_stream_table()});
 const std::vector<RVariant> kStreamCheck = variants_of({yalps_stream_check_table()});
+// sweep_kernel<lanes, units, hasCycle>: persistent, in place, for what streams from HBM (rows of 8194 .. 16385 columns, and
+// 4098 .. 8193-column tableaux beyond the Infinity Cache)
+const std::vector<RVariant> kSweep = variants_of({yalps_sweep_table()});
+const std::vector<RVariant> kSweepCheck = variants_of({yalps_sweep_check_table()});
+constexpr size_t SWEEP_BEYOND_CACHE = 200u << 20; // tableau bytes from which row traffic goes non-temporal (Infinity Cache: 256 MiB)
 constexpr int RESIDENT_CHUNK = 4096; // pivots per launch of the resident kernel (bounds its run time)
 
 struct YalpsNcclId { // ncclUniqueId (rccl.h: 128 opaque bytes, passed by value)
@@ -247,6 +252,7 @@ struct yalps_tableau {
     size_t rc_sync_bytes = 0;
     RVariant svar{0, 0, 0, nullptr}; // stream_kernel variant (persistent, in place)
     RVariant svar_check{0, 0, 0, nullptr}; // the same with hasCycle (options.checkCycles)
+    bool sweep = false;                    // svar / svar_check are sweep_kernel variants
     bool sattr_check = false;
     size_t sshmem = 0;
     bool sattr = false;
@@ -623,6 +629,30 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
             if (v.T == T && v.J == J) t->svar_check = v;
         t->sshmem = sizeof(double) * ((size_t)d.pitch + 3 * (size_t)rows_per_block) + sizeof(int32_t) * (size_t)rows_per_block;
         if (t->sshmem > 150 * 1024) t->svar.fn = t->svar_check.fn = nullptr;
+        // what streams from HBM anyway goes to sweep_kernel: rows of 8194 .. 16385 columns (no stream_kernel spans them), and
+        // 4098 .. 8193-column tableaux too big for the Infinity Cache (measured at 8193 x 8193: stream_kernel 5.1 TB/s)
+        const size_t tab_bytes = sizeof(double) * (size_t)d.pitch * hcap;
+        const int sweep_mode = env_int("YALPS_HIP_SWEEP", 1); // 0: never, 1: by size, 2: wherever a variant exists
+        if (sweep_mode && (J == 8 || (J == 4 && (tab_bytes > SWEEP_BEYOND_CACHE || sweep_mode == 2)))) {
+            const size_t lds = sizeof(double) * 2 * 512 * (size_t)(2 * J) + (4 * sizeof(double) + sizeof(int32_t)) * (size_t)rows_per_block + 64;
+            if (lds <= 150 * 1024) {
+                int want_nt = tab_bytes > SWEEP_BEYOND_CACHE ? 1 : 0;
+                if (const char *e = std::getenv("YALPS_HIP_SWEEP_NT")) want_nt = std::atoi(e) != 0;
+                const int sT = 512, sJ = 2 * J; // (sweep_kernel runs 512 lanes x 8 / 16 units: persistent_sweep.hip)
+                for (const RVariant &v : kSweep)
+                    if (v.T == sT && v.J == sJ && v.R == want_nt) {
+                        t->svar = v;
+                        t->sweep = true;
+                    }
+                if (t->sweep) {
+                    t->svar_check.fn = nullptr;
+                    for (const RVariant &v : kSweepCheck)
+                        if (v.T == sT && v.J == sJ && v.R == want_nt) t->svar_check = v;
+                    t->sshmem = lds;
+                    d.sw_nt = want_nt;
+                }
+            }
+        }
     }
     if (t->rvar.fn || t->svar.fn) {
         for (int k = 0; k < 2; k++) {
@@ -640,7 +670,8 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
                 if (v.T == t->rvar.T && v.J == t->rvar.J && v.R == t->rvar.R) t->rvar_tag = v;
         const size_t tag_row = 2 * (size_t)d.pitch + 2;
         const size_t tag_bytes = t->rvar_tag.fn ? sizeof(double) * 2 * (size_t)t->nb * tag_row : 0;
-        t->rc_sync_bytes = sizeof(unsigned long long) * (2 * nflag + 2) + tag_bytes + 16; // (a multiple of 16)
+        const size_t sweep_bytes = t->sweep ? ((size_t)yalps_sweep_sync_bytes() + 15) / 16 * 16 + 32 * 2 * (size_t)t->nb : 0;
+        t->rc_sync_bytes = sizeof(unsigned long long) * (2 * nflag + 2) + tag_bytes + sweep_bytes + 16; // (a multiple of 16)
         HIP_TRY(hipMalloc(&t->ctl_block, t->rc_sync_bytes + 2 * sizeof(YState) + sizeof(YConst)));
         HIP_TRY(hipMemsetAsync(t->ctl_block, 0, t->rc_sync_bytes + 2 * sizeof(YState) + sizeof(YConst), s));
         t->rc_sync = t->ctl_block;
@@ -651,6 +682,11 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
         if (t->rvar_tag.fn) {
             d.rc_tag[0] = reinterpret_cast<double *>(base + 2 * nflag + 2);
             d.rc_tag[1] = d.rc_tag[0] + (size_t)t->nb * tag_row;
+        }
+        if (t->sweep) {
+            char *sw = reinterpret_cast<char *>(base + 2 * nflag + 2) + tag_bytes;
+            d.sw_sync = reinterpret_cast<unsigned long long *>(sw);
+            d.sw_recs = reinterpret_cast<unsigned long long *>(sw + ((size_t)yalps_sweep_sync_bytes() + 15) / 16 * 16);
         }
         char *tail = static_cast<char *>(t->ctl_block) + t->rc_sync_bytes;
         d.rc_err = reinterpret_cast<int32_t *>(tail - 16);
@@ -714,7 +750,7 @@ int32_t yalps_tableau_info(const yalps_tableau *t, char *buf, int32_t len) {
     if (t->rvar.fn)
         std::snprintf(res, sizeof res, "resident%s_kernel<%d,%d,%d%s> chunk=%d lds_rows=%d", t->rgen == 2 && !t->rvar_tag.fn ? "2" : "", t->rvar.T, t->rvar.J, t->rvar.R,
                       t->d.extra ? ",lds" : t->rvar_tag.fn ? ",tag" : "", RESIDENT_CHUNK, t->d.extra);
-    if (t->svar.fn) std::snprintf(inp, sizeof inp, "stream_kernel<%d,%d>", t->svar.T, t->svar.J);
+    if (t->svar.fn) std::snprintf(inp, sizeof inp, "%s_kernel<%d,%d%s>", t->sweep ? "sweep" : "stream", t->svar.T, t->svar.J, t->sweep && t->d.sw_nt ? ",nt" : "");
     char str[64];
     if (t->wfn)
         std::snprintf(str, sizeof str, "wide_kernel<%d,%d>", t->var.T, t->var.J);
@@ -1105,7 +1141,12 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
         t->last_launches = 1;
         return run_small(c, sd, checkCycles, result_out, pivots_out, gpu_ms_out);
     }
-    if (t->generic || (t->prefer_generic && t->d.nshards == 1))
+    // (a path switched off by a give-up comes back after PERSISTENT_RETRY_AFTER solves)
+    const bool resident_on = c->resident && (c->resident_skip == 0 || --c->resident_skip == 0);
+    const bool inplace_on = c->inplace && (c->inplace_skip == 0 || --c->inplace_skip == 0);
+    // (rows of 8194 .. 16385 columns: sweep_kernel where it applies, else the any-shape pair)
+    const bool sweep_ok = t->sweep && t->d.nshards == 1 && inplace_on && (checkCycles ? t->svar_check.fn : t->svar.fn);
+    if (t->generic || (t->prefer_generic && t->d.nshards == 1 && !sweep_ok))
         return solve_generic(t, precision, maxPivots, checkCycles, result_out, pivots_out, gpu_ms_out);
     const int which = checkCycles ? 1 : 0;
     int rc = init_state(t, precision, maxPivots, checkCycles, false);
@@ -1121,9 +1162,6 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
     //     fits on chip, else the in-place streaming kernel
     // (fall-back order: resident -> in place -> one launch per pivot; a path that fails is not tried again on this context)
     int64_t hist_have = 0; // checkCycles: pivots recorded in the current phase at the next launch's start
-    // (a path switched off by a give-up comes back after PERSISTENT_RETRY_AFTER solves)
-    const bool resident_on = c->resident && (c->resident_skip == 0 || --c->resident_skip == 0);
-    const bool inplace_on = c->inplace && (c->inplace_skip == 0 || --c->inplace_skip == 0);
     for (int attempt = 0; attempt < 2 && !finished; attempt++) {
         const bool persistent_ok = t->d.nshards == 1;
         const bool use_resident = persistent_ok && resident_on && c->resident_skip == 0 && t->rvar.fn; // (checkCycles: one more exchange per pivot)
