@@ -485,14 +485,15 @@ __global__ __launch_bounds__(T) void resident2_kernel(Desc d, int parity, int ch
         // the R + 1 divisions of the pivot column and my rows' RHS entries: lane g of wave 0 for row g
         double my_nq = 0.0;
         if (wave == 0) {
-            if (tid < R) {
-                my_nq = -my_coef / q; // :36
-                sh_nq[tid] = my_nq;
-            } else if (tid == R + 1) {
-                sh_nq[R + 1] = 1.0 / q; // :25
-            }
+            // ONE division sequence for all three kinds of quotient: lane g < R: -coef_g / q (:36), lane R + 1: 1 / q (:25),
+            // lane R + 2: RHS_row / q (:20 at column 0) -- three sequences, one per branch, kept wave 0 behind the others
+            const double num = tid < R ? -my_coef : tid == R + 1 ? 1.0 : rhs_row;
+            const double quot = num / q;
+            my_nq = quot;
+            if (tid < R || tid == R + 1) sh_nq[tid] = quot;
+            const double rhs_q = lane_f64(quot, R + 2);
             if (my_live) { // RHS entry of my row (:33 at column 0)
-                const double pn_rhs = nz_rhs ? rhs_row / q : 0.0;
+                const double pn_rhs = nz_rhs ? rhs_q : 0.0;
                 if (tid == lslot)
                     my_rhs = pn_rhs;
                 else if (fabs(my_coef) > 1e-16 && nz_rhs) {
