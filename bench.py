@@ -74,7 +74,7 @@ def measured_traffic(size, resident, pivots_per_launch):
     """HBM bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, corrected as
     MI355X_MICROARCH.md prescribes), collected in separate rocprofv3 --pmc passes of this same
     workload and committed under profiles/ -- bench.py cannot run the profiler on itself."""
-    name = "r01_pmc_traffic_resident.json" if resident else "r01_pmc_traffic.json"
+    name = "r02_pmc_traffic_resident.json" if resident else "r01_pmc_traffic.json"
     path = os.path.join(ROOT, "profiles", name)
     if size != 2048 or not os.path.exists(path):
         return None

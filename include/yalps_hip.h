@@ -125,6 +125,17 @@ int32_t yalps_tableau_copy(yalps_tableau *dst, const yalps_tableau *src);
  * A branch-and-cut node then costs no PCIe traffic beyond its cuts, column 0 and the permutations. */
 int32_t yalps_tableau_apply_cuts(yalps_tableau *dst, const yalps_tableau *root, int32_t ncuts,
                                  const int32_t *cut_sign, const int32_t *cut_variable, const double *cut_value);
+/* One branch-and-cut node in one call (src/branchAndCut.ts:126-127 `applyCuts` + `simplex` on the node, then what
+ * `mostFractionalVar` / `solution()` read of it): dst = root + cuts as yalps_tableau_apply_cuts builds it, solved, column 0
+ * (root height + ncuts doubles) and both permutations (width + root height + ncuts entries) copied back when the node is
+ * optimal.  Where the node's tableau takes the register-resident kernel the whole sequence is three kernel launches
+ * and one wait (node_prepare_kernel: copies + cuts + state, the solve, node_finish_kernel: results into pinned host
+ * memory) instead of eleven stream operations; otherwise it is the same calls one by one.  Returns the SolutionStatus
+ * code or a negative error. */
+int32_t yalps_tableau_node_solve(yalps_tableau *dst, const yalps_tableau *root, int32_t ncuts, const int32_t *cut_sign,
+                                 const int32_t *cut_variable, const double *cut_value, double precision, double maxPivots,
+                                 int32_t checkCycles, double *result_out, double *col0_out, int32_t *positionOfVariable_out,
+                                 int32_t *variableAtPosition_out);
 int32_t yalps_tableau_height(const yalps_tableau *t);
 /* Which kernels this tableau uses and which path the last solve took (text, for benchmarks). */
 int32_t yalps_tableau_info(const yalps_tableau *t, char *buf, int32_t len);

@@ -133,6 +133,51 @@ def test_device_apply_cuts_matches_host(nat, oracle, name):
         ctx.close()
 
 
+@pytest.mark.parametrize("name", ["Large Farm MIP", "Monster 2", "Vendor Selection"])
+def test_node_solve_fused_equals_call_by_call_and_oracle(nat, oracle, name, monkeypatch):
+    """yalps_tableau_node_solve (src/branchAndCut.ts:126-127 on one node: applyCuts + simplex + column 0 and both permutations
+    back): the fused form (node_prepare_kernel, the resident kernel, node_finish_kernel -- nodes that take the resident kernel:
+    Monster 2, Vendor Selection) against the same node call by call, and both against the oracle on the host-built node
+    tableau -- status, result, column 0 and permutations bit for bit; every count of cuts twice (staging reuse)."""
+    from tests.test_host_model import oracle_backend
+    case = K.load(name)
+    tabmod = M.tableau_model(case["model"])
+    t = tabmod.tableau
+    opt = {**S.default_options, **case["options"]}
+    status, result = oracle_backend(oracle)(t, opt)
+    assert status == "optimal"
+    nodes = _collect_nodes(oracle, tabmod, result, opt, 14)
+    nodes = nodes + nodes[::-1]  # (every count of cuts at least twice: capture, then replays)
+    extra = 2 * len(tabmod.integers)
+    ctx = nat.Context(0)
+    root, node = nat.DeviceTableau(ctx, t.width, t.height), nat.DeviceTableau(ctx, t.width, t.height + extra)
+    buf = (np.zeros(t.matrix.size + extra * t.width), np.zeros(t.width + t.height + extra, np.int32),
+           np.zeros(t.width + t.height + extra, np.int32))
+    try:
+        root.upload(t.matrix, t.height, t.position_of_variable, t.variable_at_position)
+        for cuts in nodes:
+            cur = BC.apply_cuts(t, buf, cuts)
+            mm, pp, vv = cur.matrix.copy(), cur.position_of_variable.copy(), cur.variable_at_position.copy()
+            est, eres, _, _ = oracle.simplex(mm, cur.width, cur.height, pp, vv, precision=opt["precision"],
+                                             max_pivots=opt["maxPivots"], check_cycles=opt["checkCycles"])
+            got = {}
+            for fused in ("1", "0"):
+                monkeypatch.setenv("YALPS_HIP_NODE_FUSED", fused)
+                st, res, hgt, col0, pos, var = node.node_solve(root, cuts, opt["precision"], opt["maxPivots"], opt["checkCycles"])
+                assert (st, hgt) == (est, cur.height) and G.same_number(res, eres), (cuts, fused)
+                if st == "optimal":
+                    assert np.array_equal(col0.view(np.int64), mm.reshape(cur.height, cur.width)[:, 0].copy().view(np.int64)), (cuts, fused)
+                    assert np.array_equal(pos, pp) and np.array_equal(var, vv), (cuts, fused)
+                got[fused] = (node.info()["last_path"], int(node.info()["node_fused_runs"]))
+            assert got["1"][0] == got["0"][0]
+        if name != "Large Farm MIP":  # (its nodes fit the LDS of one CU: small_kernel, call by call)
+            assert got["1"][1] == len(nodes), got
+    finally:
+        node.close()
+        root.close()
+        ctx.close()
+
+
 @pytest.mark.parametrize("name", INTEGER_CASES)
 def test_device_nodes_solve_equals_sequential(nat, name):
     """The whole MILP with root and nodes resident in HBM (forced for every integer case, whatever its size)

@@ -33,3 +33,10 @@ def bare():
     node.apply_cuts(root, cuts)
     return lib.yalps_tableau_solve(node.handle, 1e-8, 1e9, 0, C.byref(res), C.byref(npiv), None)
 print("apply+solve (no timing events) us", tm_(bare))
+
+def one_call():
+    return node.node_solve(root, cuts, max_pivots=1e9)
+os.environ["YALPS_HIP_NODE_FUSED"] = "0"
+print("node_solve, call by call us", tm_(one_call), one_call()[0])
+os.environ["YALPS_HIP_NODE_FUSED"] = "1"
+print("node_solve, fused (3 launches) us", tm_(one_call), one_call()[0])

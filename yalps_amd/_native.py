@@ -22,7 +22,7 @@ SYMBOLS = (
     "yalps_tableau_solve", "yalps_tableau_pivot", "yalps_tableau_bench_sweep", "yalps_dense_lp_f64",
     "yalps_round_to_precision", "yalps_ctx_create_on_stream", "yalps_tableau_set_shard", "yalps_shard_slot_doubles",
     "yalps_shard_begin", "yalps_shard_select", "yalps_shard_apply", "yalps_shard_poll", "yalps_tableau_info",
-    "yalps_tableau_assemble", "yalps_simplex_sparse_f64", "yalps_tableau_apply_cuts", "yalps_tableau_download_solution", "yalps_milp_f64", "yalps_batch_create", "yalps_batch_destroy", "yalps_batch_set_root", "yalps_batch_solve", "yalps_batch_download",
+    "yalps_tableau_assemble", "yalps_simplex_sparse_f64", "yalps_tableau_apply_cuts", "yalps_tableau_node_solve", "yalps_tableau_download_solution", "yalps_milp_f64", "yalps_batch_create", "yalps_batch_destroy", "yalps_batch_set_root", "yalps_batch_solve", "yalps_batch_download",
     "yalps_tableau_debug_stamps", "yalps_comm_unique_id", "yalps_comm_create", "yalps_comm_create_host", "yalps_comm_destroy",
     "yalps_comm_info", "yalps_shard_run",
 )
@@ -65,6 +65,8 @@ def lib():
         L.yalps_tableau_download_solution.argtypes = [vp, vp, vp, vp]
         L.yalps_tableau_apply_cuts.restype = C.c_int32
         L.yalps_tableau_apply_cuts.argtypes = [vp, vp, C.c_int32, vp, vp, vp]
+        L.yalps_tableau_node_solve.restype = C.c_int32
+        L.yalps_tableau_node_solve.argtypes = [vp, vp, C.c_int32, vp, vp, vp, C.c_double, C.c_double, C.c_int32, C.POINTER(C.c_double), vp, vp, vp]
         L.yalps_tableau_assemble.restype = C.c_int32
         L.yalps_tableau_assemble.argtypes = [vp, C.c_int32, C.c_int64, vp, vp, vp]
         L.yalps_ctx_create.restype = C.c_int32
@@ -270,6 +272,21 @@ class DeviceTableau:
         val = np.array([c[2] for c in cuts] or [0.0], np.float64)
         check(lib().yalps_tableau_apply_cuts(self.handle, root.handle, len(cuts), sign.ctypes.data, var.ctypes.data,
                                              val.ctypes.data))
+
+    def node_solve(self, root, cuts, precision=1e-8, max_pivots=8192.0, check_cycles=False):
+        """applyCuts + simplex + what solution() reads, one native call (yalps_tableau_node_solve: three launches and one wait where the
+        node takes the resident kernel).  Returns (status, result, height, col0, pos, var);
+        the three arrays are meaningful for an optimal node."""
+        sign = np.array([c[0] for c in cuts] or [0], np.int32)
+        var = np.array([c[1] for c in cuts] or [0], np.int32)
+        val = np.array([c[2] for c in cuts] or [0.0], np.float64)
+        h = root.height + len(cuts)
+        col0, p, v = np.empty(h), np.empty(self.width + h, np.int32), np.empty(self.width + h, np.int32)
+        res = C.c_double()
+        st = check(lib().yalps_tableau_node_solve(self.handle, root.handle, len(cuts), sign.ctypes.data, var.ctypes.data, val.ctypes.data,
+                                                  precision, float(max_pivots), int(bool(check_cycles)), C.byref(res),
+                                                  col0.ctypes.data, p.ctypes.data, v.ctypes.data))
+        return STATUS[st], res.value, h, col0, p, v
 
     def solve(self, precision=1e-8, max_pivots=8192.0, check_cycles=False, timing=True):
         """Returns (status, result, n_pivots, gpu_ms); timing=False skips the HIP events (gpu_ms = 0)."""

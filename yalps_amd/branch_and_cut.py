@@ -260,14 +260,12 @@ def branch_and_cut_device(tabmod, root, node, init_result, options, stats=None):
         relaxed_eval, cuts = br.eval, br.cuts
         if relaxed_eval > best_eval:
             break
-        node.apply_cuts(root, cuts)
-        status, result, npiv, _ = node.solve(precision, options["maxPivots"], options["checkCycles"], timing=False)
+        # applyCuts + simplex + column 0 / permutations back: one native call (three launches, one wait)
+        status, result, node_height, col0, pos, var = node.node_solve(root, cuts, precision, options["maxPivots"], options["checkCycles"])
         if stats is not None:
             stats["device_nodes"] += 1
-            stats["pivots"] += npiv
         if status == "optimal" and result < best_eval:
-            col0, pos, var = node.download_solution()
-            current = Tableau(None, tableau.width, node.height, pos, var, col0)
+            current = Tableau(None, tableau.width, node_height, pos, var, col0)
             variable, value, frac = most_fractional_var(current, integers)
             if frac <= precision:
                 solution_found, best_eval, best_tableau = True, result, current

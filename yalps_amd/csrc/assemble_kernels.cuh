@@ -64,3 +64,78 @@ __global__ __launch_bounds__(256) void apply_cuts_kernel(Desc dst, const double 
             dst.var[k] = k;
         }
 }
+
+// One branch-and-cut node's whole preparation in ONE launch (what used to be three root -> node copies, the cuts' upload,
+// apply_cuts_kernel, the state block's upload and the memset of the hand-off words: seven stream operations, each a kernel
+// of its own in the runtime with ~4.5 us between dependent ones): workgroups [0, ncuts) build the cut rows exactly as
+// apply_cuts_kernel does, reading the cuts straight from pinned host memory (`stage`: [st0 | st1 | cst] then value[ncuts] |
+// sign[ncuts] | variable[ncuts]); every workgroup then takes its share of the copies (root rows [0, h0), RHS, both
+// permutations), zeroes the hand-off words and moves the state block into place.  Reads root buffers only, writes dst only.
+__global__ __launch_bounds__(256) void node_prepare_kernel(Desc dst, const double *__restrict__ root_mat,
+                                                           const double *__restrict__ root_rhs,
+                                                           const int32_t *__restrict__ root_pos,
+                                                           const int32_t *__restrict__ root_var, int h0, int ncuts,
+                                                           const char *__restrict__ stage, int state_bytes,
+                                                           unsigned long long *__restrict__ sync, long long sync_words) {
+    const int b = blockIdx.x, tid = threadIdx.x, w = dst.w, n = dst.n, pitch = dst.pitch;
+    if (b < ncuts) {
+        const double *cut_val = reinterpret_cast<const double *>(stage + state_bytes);
+        const int32_t *cut_sign = reinterpret_cast<const int32_t *>(cut_val + ncuts), *cut_var = cut_sign + ncuts;
+        const double sign = (double)cut_sign[b], value = cut_val[b];
+        const int p = root_pos[cut_var[b]];
+        double *row = dst.mat[0] + (size_t)(h0 + b) * pitch;
+        if (p < w) { // non-basic at the root: sign * x <= sign * value   (src/branchAndCut.ts:32-35)
+            for (int c = tid; c < pitch; c += 256) row[c] = (c == p - 1) ? sign : 0.0;
+            if (tid == 0) dst.rhs[0][h0 + b] = sign * value;
+        } else { // basic in root row p - w: substitute that row   (:36-42)
+            const double *src = root_mat + (size_t)(p - w) * pitch;
+            for (int c = tid; c < pitch; c += 256) row[c] = c < n ? -sign * src[c] : 0.0;
+            if (tid == 0) dst.rhs[0][h0 + b] = sign * (value - root_rhs[p - w]);
+        }
+    }
+    const long long gid = (long long)b * 256 + tid, gsz = (long long)gridDim.x * 256;
+    { // rows [0, h0): pitch is a multiple of 16 doubles, the rows are contiguous
+        const int4 *src = reinterpret_cast<const int4 *>(root_mat);
+        int4 *out = reinterpret_cast<int4 *>(dst.mat[0]);
+        const long long words = (long long)pitch * h0 / 2;
+        for (long long i = gid; i < words; i += gsz) out[i] = src[i];
+    }
+    for (long long i = gid; i < h0; i += gsz) dst.rhs[0][i] = root_rhs[i];
+    for (long long i = gid; i < w + h0; i += gsz) { // :46-52: the old entries, then the new rows' slacks (identity)
+        dst.pos[i] = root_pos[i];
+        dst.var[i] = root_var[i];
+    }
+    for (long long i = gid; i < ncuts; i += gsz) {
+        dst.pos[w + h0 + i] = (int32_t)(w + h0 + i);
+        dst.var[w + h0 + i] = (int32_t)(w + h0 + i);
+    }
+    for (long long i = gid; i < sync_words; i += gsz) sync[i] = 0ull;
+    if (b == gridDim.x - 1) {
+        const int4 *src = reinterpret_cast<const int4 *>(stage);
+        int4 *out = reinterpret_cast<int4 *>(dst.st);
+        for (int i = tid; i < state_bytes / 16; i += 256) out[i] = src[i];
+    }
+}
+
+// ... and what comes back, in ONE launch instead of three device -> host copies: [error word | st0 | st1] into `ctl_out`,
+// column 0 of the buffer the final state names and both permutations into `out` (pinned host memory, written over PCIe;
+// layout of yalps_tableau_download_solution's staging: col0[h] | pos[perm_len] ... var at perm_cap).
+__global__ __launch_bounds__(256) void node_finish_kernel(Desc d, int h, int perm_len, int perm_cap, int ctl_bytes,
+                                                          char *__restrict__ ctl_out, char *__restrict__ out) {
+    const int gid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
+    if (blockIdx.x == 0) {
+        const int4 *src = reinterpret_cast<const int4 *>(d.rc_err);
+        int4 *dstw = reinterpret_cast<int4 *>(ctl_out);
+        for (int i = threadIdx.x; i < ctl_bytes / 16; i += 256) dstw[i] = src[i];
+    }
+    const int mbuf = d.st[1].mbuf & 1;
+    const double *rhs = d.rhs[mbuf];
+    double *col0 = reinterpret_cast<double *>(out);
+    for (int i = gid; i < h; i += gsz) col0[i] = rhs[i];
+    int32_t *pos = reinterpret_cast<int32_t *>(out + sizeof(double) * (size_t)h), *var = pos + perm_cap;
+    for (int i = gid; i < perm_len; i += gsz) {
+        pos[i] = d.pos[i];
+        var[i] = d.var[i];
+    }
+}
+

@@ -295,6 +295,11 @@ struct yalps_tableau {
     int32_t *fetch_pos = nullptr, *fetch_var = nullptr;
     bool fetch_done = false;
     int64_t cells_cap = 0;
+    // branch-and-cut nodes built from a root next door (node_fused_solve)
+    void *cut_pin = nullptr; // pinned staging of a node's state block and cuts, read by node_prepare_kernel over PCIe
+    size_t cut_pin_bytes = 0;
+    bool node_occupancy_ok = false;
+    int64_t node_fused_runs = 0;
 };
 
 namespace {
@@ -726,6 +731,7 @@ void yalps_tableau_destroy(yalps_tableau *t) {
         if (t->graph_exec[k]) (void)hipGraphExecDestroy(t->graph_exec[k]);
         if (t->graph[k]) (void)hipGraphDestroy(t->graph[k]);
     }
+    if (t->cut_pin) (void)hipHostFree(t->cut_pin);
     Desc &d = t->d;
     // (pos / var and st / cst / the hand-off words are parts of perm_block and ctl_block where those exist: ordinary tableaux)
     void *bufs[] = {d.mat[0], d.mat[1], d.rhs[0], d.rhs[1], t->perm_block ? nullptr : d.pos, t->perm_block ? nullptr : d.var, t->perm_block,
@@ -757,14 +763,14 @@ int32_t yalps_tableau_info(const yalps_tableau *t, char *buf, int32_t len) {
     else
         std::snprintf(str, sizeof str, "pivot_kernel<%d,%d,%d>", t->var.T, t->var.J, t->var.R);
     std::snprintf(buf, (size_t)len, "streaming=%s workgroups=%d resident=%s inplace=%s giveups=%lld resident_off_for=%d inplace_off_for=%d "
-                  "last_path=%s last_resident_launches=%lld", str,
+                  "last_path=%s last_resident_launches=%lld node_fused_runs=%lld", str,
                   t->nb, res, inp, (long long)t->giveups, t->ctx->resident ? t->ctx->resident_skip : -1,
                   t->ctx->inplace ? t->ctx->inplace_skip : -1,
                   t->last_path == 1 ? "resident" : t->last_path == 2 ? "streaming" : t->last_path == 3 ? "resident+streaming"
                   : t->last_path == 4 ? "small" : t->last_path == 8 ? "inplace" : t->last_path == 10 ? "inplace+streaming"
                   : t->last_path == 9 ? "resident+inplace" : t->last_path == 11 ? "resident+inplace+streaming"
                   : t->last_path == 16 ? "generic" : "none",
-                  (long long)(t->last_path & 9 ? t->last_launches : 0));
+                  (long long)(t->last_path & 9 ? t->last_launches : 0), (long long)t->node_fused_runs);
     return 0;
 }
 
@@ -1372,6 +1378,147 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
     if (result_out) *result_out = fin.result;
     if (pivots_out) *pivots_out = fin.pivots;
     return fin.status;
+}
+
+// A branch-and-cut node in THREE launches and one wait (src/branchAndCut.ts:22-61 applyCuts + :127 simplex on the node):
+// what apply_cuts_impl + yalps_tableau_solve enqueue one by one for a node whose tableau takes the resident kernel --
+// three root -> node copies, the cuts, apply_cuts_kernel, the state block, the memset of the hand-off words, the kernel,
+// and three copies back: eleven stream operations, every copy a blit kernel of the runtime with ~4.5 us between dependent
+// ones (rocprof timeline: ~90 us of device time around a 15 us solve) -- as node_prepare_kernel, the resident kernel and
+// node_finish_kernel; cuts, state and results travel through pinned host memory that the kernels read and write directly.
+// (The same eleven operations captured as ONE hipGraph per number of cuts ran in exactly the same time, 70.7 vs 71.0 us per
+// Monster 2 node: the graph replays the same blit kernels with the same gaps.  YALPS_HIP_NODE_FUSED=0: call by call.)
+//   returns 1: done (*status_out, *result_out; column 0 and the basis are in the fetch_* arrays of dst);
+//           0: not for this node, or the launch did not finish the solve (give-up, > chunk pivots): the caller runs
+//              the node through the ordinary calls, which rebuild it from the root;
+//         < 0: error.
+static int32_t node_fused_solve(yalps_tableau *dst, const yalps_tableau *root, int32_t ncuts, const int32_t *cut_sign,
+                                const int32_t *cut_variable, const double *cut_value, double precision, double maxPivots,
+                                int32_t checkCycles, double *result_out, int32_t *status_out) {
+    yalps_ctx *c = dst->ctx;
+    const bool enabled = env_int("YALPS_HIP_NODE_FUSED", 1) != 0; // (read per call: tests compare both ways in one process)
+    if (!enabled || checkCycles || ncuts < 1 || !dst->fetch_col0 || !dst->ctl_block || !dst->perm_block || !root->perm_block ||
+        dst->generic || dst->d.nshards != 1 || root->d.nshards != 1 || dst->d.w != root->d.w || dst->ctx != root->ctx ||
+        (int64_t)root->height + ncuts > dst->d.hcap || !c->resident || c->resident_skip != 0 || c->resident_fault > 0 ||
+        !dst->rvar.fn || fits_small(c, dst->d.w, root->height + ncuts))
+        return 0;
+    for (int32_t i = 0; i < ncuts; i++)
+        if (cut_variable[i] < 0 || cut_variable[i] >= root->d.w + root->height)
+            return fail(YALPS_E_ARG, "yalps_tableau_apply_cuts: cut on an unknown variable");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int32_t h0 = root->height, h = h0 + ncuts;
+    constexpr size_t STATE_BYTES = 2 * sizeof(YState) + sizeof(YConst);
+    static_assert(STATE_BYTES % 16 == 0 && (16 + 2 * sizeof(YState)) % 16 == 0, "moved as 16-byte words");
+    if (STATE_BYTES + (size_t)ncuts * 16 > dst->cut_pin_bytes) {
+        HIP_TRY(hipStreamSynchronize(s));
+        if (dst->cut_pin) HIP_TRY(hipHostFree(dst->cut_pin));
+        dst->cut_pin = nullptr;
+        dst->cut_pin_bytes = 0;
+        const size_t cap = STATE_BYTES + ((size_t)ncuts + 1024) * 16;
+        HIP_TRY(hipHostMalloc(&dst->cut_pin, cap, hipHostMallocDefault));
+        dst->cut_pin_bytes = cap;
+    }
+    // the tableau object as apply_cuts_impl + init_state leave it
+    dst->cur = 0;
+    dst->height = h;
+    dst->perm_len = dst->d.w + h;
+    dst->d.perm_len = dst->perm_len;
+    if (int rc = ensure_pin_out(dst)) return rc;
+    char *stage = static_cast<char *>(dst->cut_pin); // [st0 | st1 | cst] value[ncuts] | sign[ncuts] | variable[ncuts]
+    {
+        YConst hc;
+        std::memset(&hc, 0, sizeof hc);
+        hc.height = h;
+        hc.precision = precision;
+        hc.max_pivots = maxPivots;
+        YState hs;
+        std::memset(&hs, 0, sizeof hs);
+        hs.status = RUNNING;
+        hs.phase = 1;
+        hs.bootstrap = 1;
+        hs.mbuf = 0;
+        hs.result = NAN;
+        std::memcpy(stage, &hs, sizeof(YState));
+        std::memset(stage + sizeof(YState), 0, sizeof(YState));
+        std::memcpy(stage + 2 * sizeof(YState), &hc, sizeof(YConst));
+    }
+    char *cuts = stage + STATE_BYTES;
+    std::memcpy(cuts, cut_value, sizeof(double) * (size_t)ncuts);
+    std::memcpy(cuts + sizeof(double) * (size_t)ncuts, cut_sign, sizeof(int32_t) * (size_t)ncuts);
+    std::memcpy(cuts + 12 * (size_t)ncuts, cut_variable, sizeof(int32_t) * (size_t)ncuts);
+    const RVariant &pv = dst->rvar_tag.fn ? dst->rvar_tag : dst->rvar;
+    const size_t shmem = dst->rx_shmem ? dst->rx_shmem : sizeof(int32_t) * 2 * (size_t)dst->perm_len;
+    if (shmem != dst->rshmem) {
+        if (shmem > 48 * 1024)
+            if (int rc2 = allow_big_lds(c->device, reinterpret_cast<const void *>(pv.fn))) return rc2;
+        dst->rshmem = shmem;
+    }
+    if (!dst->node_occupancy_ok) {
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(pv.fn), pv.T, shmem));
+        if (per_cu < 1 || dst->nb > c->num_cus * per_cu) return 0; // (the ordinary path reports it and moves on)
+        dst->node_occupancy_ok = true;
+    }
+    const int prep_blocks = std::max<int>(ncuts, (int)std::min<int64_t>(1024, ((int64_t)root->d.pitch * h0 / 2 + 255) / 256));
+    node_prepare_kernel<<<dim3(prep_blocks), dim3(256), 0, s>>>(dst->d, root->d.mat[root->cur], root->d.rhs[root->cur], root->d.pos, root->d.var, h0,
+                                                               ncuts, stage, (int)STATE_BYTES, static_cast<unsigned long long *>(dst->rc_sync),
+                                                               (long long)(dst->rc_sync_bytes / 8));
+    HIP_TRY(hipGetLastError());
+    {
+        std::lock_guard<std::mutex> one_grid(persistent_mutex(c->device));
+        DeviceLock one_grid_of_all_processes(c->lock_fd);
+        pv.fn<<<dim3(dst->nb), dim3(pv.T), shmem, s>>>(dst->d, 0, c->resident_chunk);
+        HIP_TRY(hipGetLastError());
+        node_finish_kernel<<<dim3(8), dim3(256), 0, s>>>(dst->d, h, dst->perm_len, dst->perm_cap, (int)(16 + 2 * sizeof(YState)), dst->host_ctl,
+                                                         static_cast<char *>(dst->pin_out));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    dst->last_path = 1;
+    dst->last_launches = 1;
+    c->persistent_launches++;
+    dst->node_fused_runs++;
+    const int32_t err = *reinterpret_cast<const int32_t *>(dst->host_ctl);
+    const YState fin = reinterpret_cast<const YState *>(dst->host_ctl + 16)[1];
+    if (err || fin.status == RUNNING) return 0;
+    const size_t f_ncol = sizeof(double) * (size_t)h, f_nperm = sizeof(int32_t) * (size_t)dst->perm_len;
+    const char *res = static_cast<const char *>(dst->pin_out);
+    std::memcpy(dst->fetch_col0, res, f_ncol);
+    std::memcpy(dst->fetch_pos, res + f_ncol, f_nperm);
+    std::memcpy(dst->fetch_var, res + f_ncol + sizeof(int32_t) * (size_t)dst->perm_cap, f_nperm);
+    dst->fetch_done = true;
+    dst->cur = fin.mbuf;
+    if (result_out) *result_out = fin.result;
+    *status_out = fin.status;
+    return 1;
+}
+
+int32_t yalps_tableau_node_solve(yalps_tableau *node, const yalps_tableau *root, int32_t ncuts, const int32_t *cut_sign,
+                                 const int32_t *cut_variable, const double *cut_value, double precision, double maxPivots,
+                                 int32_t checkCycles, double *result_out, double *col0_out, int32_t *pos_out, int32_t *var_out) {
+    if (!node || !root || !col0_out || !pos_out || !var_out) return fail(YALPS_E_ARG, "yalps_tableau_node_solve: NULL argument");
+    // column 0 and the permutations ride along with the solve's own wait where the persistent path allows it
+    node->fetch_col0 = col0_out;
+    node->fetch_pos = pos_out;
+    node->fetch_var = var_out;
+    node->fetch_done = false;
+    int32_t st = 0;
+    int32_t rc = 0;
+    if (node != root && ncuts >= 1 && cut_sign && cut_variable && cut_value)
+        rc = node_fused_solve(node, root, ncuts, cut_sign, cut_variable, cut_value, precision, maxPivots, checkCycles, result_out, &st);
+    if (rc == 0) {
+        node->fetch_done = false;
+        rc = apply_cuts_impl(node, root, ncuts, cut_sign, cut_variable, cut_value, false); // (the solve below waits)
+        if (rc == 0) st = yalps_tableau_solve(node, precision, maxPivots, checkCycles, result_out, nullptr, nullptr);
+    }
+    const bool fetched = node->fetch_done;
+    node->fetch_col0 = nullptr;
+    node->fetch_pos = node->fetch_var = nullptr;
+    if (rc < 0) return rc;
+    if (st == YALPS_OPTIMAL && !fetched)
+        if (int rc2 = yalps_tableau_download_solution(node, col0_out, pos_out, var_out)) return rc2;
+    return st;
 }
 
 static int32_t set_decision(yalps_tableau *t, int32_t row, int32_t col) {

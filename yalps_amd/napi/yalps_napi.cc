@@ -49,6 +49,8 @@ int32_t (*g_tab_download_rhs)(void *, double *) = nullptr;
 int32_t (*g_tab_height)(const void *) = nullptr;
 int32_t (*g_tab_solve)(void *, double, double, int32_t, double *, int64_t *, float *) = nullptr;
 int32_t (*g_tab_apply_cuts)(void *, const void *, int32_t, const int32_t *, const int32_t *, const double *) = nullptr;
+int32_t (*g_tab_node_solve)(void *, const void *, int32_t, const int32_t *, const int32_t *, const double *, double, double, int32_t,
+                            double *, double *, int32_t *, int32_t *) = nullptr;
 int32_t (*g_milp)(const double *, int32_t, int32_t, const int32_t *, const int32_t *, const int32_t *, int32_t, double, double, double,
                   int32_t, double, double, double, int32_t, int32_t *, double *, double *, int32_t *, int32_t *, int32_t *,
                   int64_t *) = nullptr;
@@ -85,9 +87,10 @@ bool load_library() {
     g_tab_height = reinterpret_cast<decltype(g_tab_height)>(sym("yalps_tableau_height"));
     g_tab_solve = reinterpret_cast<decltype(g_tab_solve)>(sym("yalps_tableau_solve"));
     g_tab_apply_cuts = reinterpret_cast<decltype(g_tab_apply_cuts)>(sym("yalps_tableau_apply_cuts"));
+    g_tab_node_solve = reinterpret_cast<decltype(g_tab_node_solve)>(sym("yalps_tableau_node_solve"));
     g_milp = reinterpret_cast<decltype(g_milp)>(sym("yalps_milp_f64"));
     if (!g_simplex || !g_last_error || !g_ctx_create || !g_ctx_destroy || !g_tab_create || !g_tab_destroy || !g_tab_upload ||
-        !g_tab_download || !g_tab_download_rhs || !g_tab_height || !g_tab_solve || !g_tab_apply_cuts || !g_milp) {
+        !g_tab_download || !g_tab_download_rhs || !g_tab_height || !g_tab_solve || !g_tab_apply_cuts || !g_tab_node_solve || !g_milp) {
         g_load_error = path + " does not export the yalps_* entry points of include/yalps_hip.h";
         g_simplex = nullptr;
         return false;
@@ -295,11 +298,15 @@ napi_value NodeSolve(napi_env env, napi_callback_info info) {
         npos < (size_t)r->width + h || nvar < (size_t)r->width + h)
         return fail(env, "nodeSolve: out must hold col0 (height) and both permutations (width + height)");
     double result = NAN;
-    int32_t status = g_tab_apply_cuts(r->node, r->root, (int32_t)ncuts, sign, variable, value);
-    if (status >= 0) status = g_tab_solve(r->node, o.precision, o.max_pivots, o.check_cycles ? 1 : 0, &result, nullptr, nullptr);
+    // applyCuts + simplex + column 0 / permutations of an optimal node in one native call (three launches, one wait)
+    int32_t status = g_tab_node_solve(r->node, r->root, (int32_t)ncuts, sign, variable, value, o.precision, o.max_pivots,
+                                      o.check_cycles ? 1 : 0, &result, static_cast<double *>(col0), static_cast<int32_t *>(pos),
+                                      static_cast<int32_t *>(var));
     const int32_t solved = status;
-    if (status >= 0) status = g_tab_download_rhs(r->node, static_cast<double *>(col0));
-    if (status >= 0) status = g_tab_download(r->node, nullptr, static_cast<int32_t *>(pos), static_cast<int32_t *>(var));
+    if (status > 0) { // (not optimal: the caller may still look at the tableau it was left with)
+        status = g_tab_download_rhs(r->node, static_cast<double *>(col0));
+        if (status >= 0) status = g_tab_download(r->node, nullptr, static_cast<int32_t *>(pos), static_cast<int32_t *>(var));
+    }
     if (status < 0) return fail(env, std::string("yalps_hip: ") + g_last_error());
     napi_value hv;
     napi_create_int32(env, (int32_t)h, &hv);
