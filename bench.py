@@ -275,7 +275,7 @@ def bench_sharded(args, torch, dist, rank, local_rank, world):
     rehearsal = world > torch.cuda.device_count()  # (ranks share GPU 0: RCCL refuses; the host transport over gloo instead)
 
     def run(pivots):
-        ops = sharded.HipShardOps(local, w, bounds, rank, h, ident, ident.copy(), device=local_rank)
+        ops = sharded.HipShardOps(local, w, bounds, rank, h, ident, ident.copy(), device=local_rank, private_stream=True)
         comm = sharded.native_comm(ops.ctx, rank, world, transport="host" if rehearsal else "rccl")
         if dist is not None:
             dist.barrier()

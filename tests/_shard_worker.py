@@ -35,7 +35,7 @@ def main():
         from tests._shard_numpy import NumpyShardOps
         ops = NumpyShardOps(local, w, bounds, rank, h, ident, ident.copy())
     else:
-        ops = sharded.HipShardOps(local, w, bounds, rank, h, ident, ident.copy(), device=0)
+        ops = sharded.HipShardOps(local, w, bounds, rank, h, ident, ident.copy(), device=0, private_stream=kind == "hip-native")
     del m
     if kind == "hip-native":
         ncomm = sharded.native_comm(ops.ctx, rank, world, transport="host")

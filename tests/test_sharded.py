@@ -99,7 +99,7 @@ def test_sharded_native_loop_rccl_one_rank(oracle, tmp_path, M, N, seed):
         "m = _oracle.load().dense_lp(M, N, seed)\n"
         "if seed %% 2: m.reshape(h, w)[1::3, 0] *= -0.05\n"
         "ident = np.arange(w + h, dtype=np.int32); bounds = sharded.partition(h, 1)\n"
-        "ops = sharded.HipShardOps(sharded.local_rows(m, w, h, bounds, 0), w, bounds, 0, h, ident, ident.copy(), device=0)\n"
+        "ops = sharded.HipShardOps(sharded.local_rows(m, w, h, bounds, 0), w, bounds, 0, h, ident, ident.copy(), device=0, private_stream=True)\n"
         "comm = sharded.native_comm(ops.ctx, 0, 1, transport='rccl')\n"
         "status, result, pivots = sharded.sharded_simplex_native(ops, comm, max_pivots=float('inf'), check_every=16)\n"
         "info = comm.info(); lm, pos, var = ops.download(); comm.close(); ops.close()\n"

@@ -218,6 +218,17 @@ __device__ __forceinline__ bool has_cycle(const YConst *C, int64_t hist_len, int
 // wait has lasted SPIN_GIVE_UP_TICKS: the grid is not co-resident -- a foreign kernel holds CUs -- or a workgroup died).
 // The caller then sets the error word and leaves; the host falls back to the launch-per-pivot kernels (yalps_hip.hip).
 constexpr unsigned long long SPIN_GIVE_UP_TICKS = 5000000ull; // 50 ms (a pivot's hand-off takes microseconds)
+// The register-resident kernels bound the same wait by a poll count instead: 2^16 polls of one sc1 round trip + s_sleep 2
+// each (0.8-1.5 us) = 50-100 ms.  (Same-box A/B: reading the clock in their poll loops, and a `return` of its own for the
+// row range check, cost the tall generation-1 variants 4-11 % per pivot -- 10001 x 1001: 14.7 -> 16.4 us -- through
+// register allocation alone; the range check now rides on the poll loop's existing failure exit.)
+constexpr unsigned SPIN_GIVE_UP_POLLS = 1u << 16;
+#ifdef YALPS_AB_TIME_SPIN
+#define RESIDENT_SPIN_EXPIRED(spins, t0, err) spin_expired(spins, t0, err)
+#else
+#define RESIDENT_SPIN_EXPIRED(spins, t0, err) \
+    (++(spins) > SPIN_GIVE_UP_POLLS || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+#endif
 __device__ __forceinline__ bool spin_expired(unsigned &spins, unsigned long long &t0, const int32_t *err_word) {
     if ((++spins & 63u) != 0) return false;
     const unsigned long long now = __builtin_amdgcn_s_memrealtime();

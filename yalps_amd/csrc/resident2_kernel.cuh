@@ -327,13 +327,13 @@ __global__ __launch_bounds__(T) void resident2_kernel(Desc d, int parity, int ch
             // key and tag are one 16-byte record, written by one store and read by one load
             unsigned long long f = 0;
             unsigned spins = 0;
-            unsigned long long spin_t0 = 0;
+            [[maybe_unused]] unsigned long long spin_t0 = 0;
             double2 rec;
             for (;;) {
                 rec = ld16_sc1_one(d.rc_flag[par] + 2 * tid);
                 f = (unsigned long long)__double_as_longlong(rec.y);
                 if ((unsigned)(f >> 32) == epoch) break;
-                if (spin_expired(spins, spin_t0, d.rc_err)) {
+                if (RESIDENT_SPIN_EXPIRED(spins, spin_t0, d.rc_err)) {
                     sh_fail = 1;
                     __hip_atomic_store(d.rc_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
@@ -342,6 +342,14 @@ __global__ __launch_bounds__(T) void resident2_kernel(Desc d, int parity, int ch
             }
             c.i = (int)(unsigned)f;
             c.k = rec.x;
+#ifndef YALPS_AB_RETURN_GUARD
+            // (never expected: a record that names no row of this tableau -- leave through the failure exit, with the error
+            // word set, instead of indexing with it)
+            if (c.i != INT_MAX && (unsigned)c.i >= (unsigned)h) {
+                sh_fail = 1;
+                __hip_atomic_store(d.rc_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#endif
         }
         YSTAMP(0); // wait for everybody's flag (waves 0 .. NB/64 - 1; the others go straight to the barrier)
         c = block_argmin2<T>(c, sk, si, slot); // (its barrier is the one the polling waves join)
@@ -364,10 +372,12 @@ __global__ __launch_bounds__(T) void resident2_kernel(Desc d, int parity, int ch
             continue;
         }
         const int row = c.i, owner = row % NB;
+#ifdef YALPS_AB_RETURN_GUARD
         if ((unsigned)row >= (unsigned)h) { // (never expected: a record that names no row of this tableau -- leave with the error
             if (tid == 0) __hip_atomic_store(d.rc_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // word set instead of indexing with it)
             return;
         }
+#endif
         // ---------------- the winner's raw row (sc1 loads only) ----------------------------------
         // (phase 2: the quotient M[row, la] rides along as one more 8-byte load of the same row)
         const double *src = d.rc_rows[par] + (size_t)owner * pitch;
@@ -431,11 +441,11 @@ __global__ __launch_bounds__(T) void resident2_kernel(Desc d, int parity, int ch
                 if (tid == 0) {
                     unsigned long long v = 0;
                     unsigned spins = 0;
-                    unsigned long long spin_t0 = 0;
+                    [[maybe_unused]] unsigned long long spin_t0 = 0;
                     for (;;) {
                         v = __hip_atomic_load(d.rc_verdict + par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if ((unsigned)(v >> 32) == epoch) break;
-                        if (spin_expired(spins, spin_t0, d.rc_err)) {
+                        if (RESIDENT_SPIN_EXPIRED(spins, spin_t0, d.rc_err)) {
                             sh_fail = 1;
                             __hip_atomic_store(d.rc_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             break;

@@ -41,14 +41,16 @@ def local_rows(matrix, width, height, bounds, rank):
 
 
 class HipShardOps:
-    """The per-rank steps on the GPU, enqueued on torch's current stream."""
+    """The per-rank steps on the GPU, enqueued on torch's current stream (the per-pivot torch collectives of
+    sharded_simplex are ordered with them there) or, private_stream=True, on a stream of the context's own: what the
+    native loop (run_native) wants -- torch's current stream is the null stream, which cannot be captured into a hipGraph."""
 
-    def __init__(self, local_matrix, width, bounds, rank, global_height, pos, var, device=0):
+    def __init__(self, local_matrix, width, bounds, rank, global_height, pos, var, device=0, private_stream=False):
         import torch
         self.torch = torch
         nranks = len(bounds) - 1
         local_h = 1 + bounds[rank + 1] - bounds[rank]
-        self.ctx = _native.Context(device, stream=torch.cuda.current_stream(device).cuda_stream)
+        self.ctx = _native.Context(device) if private_stream else _native.Context(device, stream=torch.cuda.current_stream(device).cuda_stream)
         self.tab = _native.DeviceTableau(self.ctx, width, local_h)
         ident = np.arange(width + local_h, dtype=np.int32)
         self.tab.upload(local_matrix, local_h, ident, ident.copy())
@@ -57,6 +59,8 @@ class HipShardOps:
         self.slot = self.tab.shard_slot_doubles()
         self.send = torch.zeros(self.slot, dtype=torch.float64, device=f"cuda:{device}")
         self.recv = torch.zeros(nranks * self.slot, dtype=torch.float64, device=f"cuda:{device}")
+        if private_stream:
+            torch.cuda.synchronize(device)  # (the buffers were zeroed on torch's stream)
 
     def begin(self, precision, max_pivots):
         self.tab.shard_begin(precision, max_pivots)
