@@ -62,17 +62,19 @@ def test_sharded_driver_gloo_cpu(oracle, tmp_path, world, M, N, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,M,N,seed", [(1, 200, 150, 4), (2, 300, 280, 5), (2, 90, 700, 2), (3, 64, 64, 9)])
+@pytest.mark.parametrize("world,M,N,seed", [(1, 200, 150, 4), (2, 300, 280, 5), (2, 90, 700, 2), (3, 64, 64, 9),
+                                            (2, 120, 3000, 6), (2, 100, 9000, 8)])
 def test_sharded_hip_steps(oracle, tmp_path, world, M, N, seed):
     """The real HIP per-rank kernels: `world` processes share the one GPU of the test box and
     exchange their candidate slots through gloo (host-staged); with RCCL on a multi-GPU node only
-    the transport differs."""
+    the transport differs.  The last two are wide enough for wide_kernel and so for its in-place shard form
+    (<1024,2,in place>, <512,16,in place>: several waves per row, rows updated where they are)."""
     res = run_world("hip", world, M, N, seed, tmp_path)
     check_against_oracle(oracle, res, M, N, seed)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,M,N,seed", [(2, 300, 280, 5), (3, 64, 64, 9)])
+@pytest.mark.parametrize("world,M,N,seed", [(2, 300, 280, 5), (3, 64, 64, 9), (2, 150, 6000, 10)])
 def test_sharded_native_loop_host_transport(oracle, tmp_path, world, M, N, seed):
     """yalps_shard_run -- select, exchange, apply and the status polls all inside the library -- with `world` processes
     sharing the test GPU; the exchange is the library's host transport (a callback) carried by gloo.  An odd pivot
@@ -82,7 +84,7 @@ def test_sharded_native_loop_host_transport(oracle, tmp_path, world, M, N, seed)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,N,seed", [(200, 150, 4), (520, 1100, 3)])
+@pytest.mark.parametrize("M,N,seed", [(200, 150, 4), (520, 1100, 3), (130, 9000, 12)])
 def test_sharded_native_loop_rccl_one_rank(oracle, tmp_path, M, N, seed):
     """The native loop over RCCL itself: ncclCommInitRank (one rank), ncclAllGather on the context's stream between the
     select and the apply kernel, every pivot enqueued by the library's own loop (one hipGraph replay per batch where the

@@ -84,6 +84,9 @@ struct Desc {
     // whether the row traffic is non-temporal (tableau beyond the Infinity Cache)
     unsigned long long *sw_sync, *sw_recs;
     int32_t sw_nt;
+    // row shards swept IN PLACE (wide_kernel<.., true, ..>): the objective row is the one row every workgroup reads while
+    // its owner rewrites it, so it alone stays ping-ponged, as two replicas [pitch] beside the tableau
+    double *obj[2];
     // diagnostic build only (-DYALPS_STAMPS, never the shipped library): [nb][STAMP_WORDS] per-workgroup stage sums in
     // shader cycles, written once when a persistent launch ends; no kernel reads it
     unsigned long long *dbg;

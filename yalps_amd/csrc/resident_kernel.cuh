@@ -816,6 +816,9 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
     }
     if (my_live) rhsB[my_r] = my_rhs;
     if (b == 0) {
+        // (the last pivot's basis swap was one lane's LDS writes at the very end of the loop body, with no barrier behind
+        // them: a wave that got here first copied the old entries -- seen once in 380 GPU tests, on a 60-pivot solve)
+        __syncthreads();
         for (int i = tid; i < d.perm_len; i += T) {
             d.var[i] = sh_perm[i];
             d.pos[i] = sh_perm[d.perm_len + i];

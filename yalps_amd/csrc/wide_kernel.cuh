@@ -16,12 +16,22 @@
 //   * the scalar side of every row (RHS entry, -coef/quotient) is computed uniformly by all
 //     lanes; the rows' entries of the next entering column and their new RHS are parked in LDS
 //     and turned into this workgroup's partial after the last row.
+// wide_kernel<T, J, true, NT> -- MODE_SHARD only -- sweeps the rows IN PLACE (one tableau buffer, no second 2 GB of DRAM
+// pages in play; rows with |coef| <= 1e-16, src/simplex.ts:31, are loaded for the look-ahead but never stored).  That is
+// safe in this mode because no workgroup reads another workgroup's rows: the pivot row arrives in the all-gathered slot,
+// my rows' pivot-column entries and RHS are gathered into LDS behind a barrier BEFORE the first row is stored (the waves
+// of a workgroup stream their column slices at their own pace: a wave that loaded them with the row, as the ping-pong form
+// does, found the entry already replaced by -coef/quotient, :36, by the wave that owns that column), and the
+// one row everybody reads -- the objective row: pricing (:71-79), phase 1's ratios (:123-134) -- is read from the
+// replica d.obj[pbuf] while workgroup 0 writes the new one to d.obj[pbuf ^ 1] (and in place).  NT: non-temporal row
+// loads as well as stores (tableaux beyond the Infinity Cache: +0.6 TB/s on the bare sweep).
 // ------------------------------------------------------------------------------------------
-template <int T, int J>
+template <int T, int J, bool INPL = false, bool NT = false>
 __global__ __launch_bounds__(T) void wide_kernel(Desc d, int parity, int mode, int force, const double *gather) {
+    constexpr int JC = J < 4 ? J : 4; // 16-byte units per lane in flight in the pivot-row / objective-row passes
     __shared__ double sk[2][16];
     __shared__ int si[2][16];
-    extern __shared__ double wd_dyn[]; // prow[pitch], lav[rpw], rhsv[rpw]
+    extern __shared__ double wd_dyn[]; // prow[pitch], lav[rpw], rhsv[rpw]; in place also colv[rpw], rin[rpw]
 
     const int tid = threadIdx.x, NB = d.nb, b = blockIdx.x;
     const YState *Sin = d.st + parity;
@@ -78,10 +88,13 @@ __global__ __launch_bounds__(T) void wide_kernel(Desc d, int parity, int mode, i
     const int pbuf = mode == MODE_FUSED ? parity : Sin->pbuf;
     const int mbuf = mode == MODE_FUSED ? parity : Sin->mbuf;
     const int la_in = Sin->la;
-    const double *__restrict__ matA = d.mat[mbuf];
-    const double *__restrict__ rhsA = d.rhs[mbuf];
-    double *__restrict__ matB = d.mat[mbuf ^ 1];
-    double *__restrict__ rhsB = d.rhs[mbuf ^ 1];
+    const double *matA = d.mat[mbuf];
+    const double *rhsA = d.rhs[mbuf];
+    double *matB = d.mat[INPL ? mbuf : mbuf ^ 1];
+    double *rhsB = d.rhs[INPL ? mbuf : mbuf ^ 1];
+    // the objective row as every workgroup reads it (in place: its replica of this parity; workgroup 0 writes the other)
+    const double *__restrict__ objA = INPL ? d.obj[pbuf] : matA;
+    double *objB = INPL ? d.obj[pbuf ^ 1] : nullptr;
     const bool bootstrap = Sin->bootstrap != 0;
     const int phase_in = Sin->phase;
     const double iter_in = Sin->iter;
@@ -89,7 +102,6 @@ __global__ __launch_bounds__(T) void wide_kernel(Desc d, int parity, int mode, i
     double iter = iter_in;
     bool phase_switched = false;
     int slot = 0;
-    const int units = pitch / 2;
 
     const int gstride = SHARD_HDR + 2 * pitch;
     const int ncand = mode == MODE_SHARD ? d.nshards : NB;
@@ -113,6 +125,19 @@ __global__ __launch_bounds__(T) void wide_kernel(Desc d, int parity, int mode, i
         return gather + (size_t)g * gstride;
     };
 
+    // In place the rows a workgroup sweeps do not depend on the decision: the first one is on its way while the serial
+    // head of the launch (decide, pivot row, pricing: ~15 us in which nothing else streams) runs.
+    [[maybe_unused]] double2 xa0[J];
+    if constexpr (INPL) {
+        if (mode == MODE_SHARD && !bootstrap) {
+            const double *m0 = matA + (size_t)(b < h ? b : 0) * pitch;
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                const int c0 = 2 * (tid + j * T), cs = c0 < pitch ? c0 : 0;
+                xa0[j] = ld_row(m0 + cs, NT);
+            }
+        }
+    }
     // ---------------- decide ------------------------------------------------------------------
     int row = 0, col = 0;
     bool have_pivot = false;
@@ -141,13 +166,28 @@ __global__ __launch_bounds__(T) void wide_kernel(Desc d, int parity, int mode, i
                 row = c.i;
                 const double *mrow1 = mode == MODE_SHARD ? owner_slot(row) + SHARD_HDR + pitch : matA + (size_t)row * pitch;
                 KI e = {INFINITY, INT_MAX};
-                for (int cc = tid; cc < n; cc += T) { // src/simplex.ts:123-134
-                    const double coefficient = mrow1[cc];
-                    if (coefficient < -precision) {
-                        const double ratio = -matA[cc] / coefficient;
-                        if (ratio > -INFINITY && ki_better(-ratio, cc + 1, e.k, e.i)) {
-                            e.k = -ratio;
-                            e.i = cc + 1;
+#pragma unroll 1
+                for (int jb = 0; jb < J; jb += JC) { // src/simplex.ts:123-134, JC 16-byte units of both rows in flight per lane
+                    double2 cr[JC], ob[JC];
+#pragma unroll
+                    for (int j = 0; j < JC; j++) {
+                        const int c0 = 2 * (tid + (jb + j) * T), cs = c0 < pitch ? c0 : 0;
+                        cr[j] = *reinterpret_cast<const double2 *>(mrow1 + cs);
+                        ob[j] = *reinterpret_cast<const double2 *>(objA + cs);
+                    }
+#pragma unroll
+                    for (int j = 0; j < JC; j++) {
+#pragma unroll
+                        for (int k = 0; k < 2; k++) {
+                            const int cc = 2 * (tid + (jb + j) * T) + k;
+                            const double coefficient = k ? cr[j].y : cr[j].x;
+                            if (cc < n && coefficient < -precision) {
+                                const double ratio = -(k ? ob[j].y : ob[j].x) / coefficient;
+                                if (ratio > -INFINITY && ki_better(-ratio, cc + 1, e.k, e.i)) {
+                                    e.k = -ratio;
+                                    e.i = cc + 1;
+                                }
+                            }
                         }
                     }
                 }
@@ -210,38 +250,56 @@ __global__ __launch_bounds__(T) void wide_kernel(Desc d, int parity, int mode, i
                      : mode != MODE_SHARD ? row
                      : (row >= d.bounds[d.shard_rank] && row < d.bounds[d.shard_rank + 1]) ? row - d.row_base : -1;
     const double q = have_pivot ? mrow[colx] : 1.0;
-    const double coef0 = have_pivot ? matA[colx] : 0.0;
+    const double coef0 = have_pivot ? objA[colx] : 0.0;
     const double rhs_row = have_pivot ? (mode == MODE_SHARD ? gslot[phase == 1 ? 5 : 4] : rhsA[row]) : 0.0;
     const double inv_q = 1.0 / q;
     const double flushed = __longlong_as_double((long long)FLUSHED);
-    for (int u = tid; u < units; u += T) {
-        double2 v = have_pivot ? *reinterpret_cast<const double2 *>(mrow + 2 * u) : make_double2(0.0, 0.0);
-        v.x = fabs(v.x) > 1e-16 ? v.x / q : flushed;
-        v.y = fabs(v.y) > 1e-16 ? v.y / q : flushed;
-        *reinterpret_cast<double2 *>(prow + 2 * u) = v;
-    }
-    __syncthreads();
+    // (a lane normalises, prices and later sweeps the same J 16-byte units of every row: all of a lane's loads of a row are
+    // in flight at once -- as run-time loops of 8-byte accesses these two passes were ~30 dependent round trips at 16385
+    // columns, during which no row streamed)
     int la = 0;
     {
         const bool touched0 = have_pivot && fabs(coef0) > 1e-16;
+        const double nq0 = -coef0 / q; // :36 for the objective row
         KI best = {INFINITY, INT_MAX};
-        for (int cc = tid; cc < n; cc += T) {
-            double ov = matA[cc];
-            if (touched0) {
-                const double pn = prow[cc];
-                if (cc == colx)
-                    ov = -coef0 / q;
-                else if ((unsigned long long)__double_as_longlong(pn) != FLUSHED) {
-                    const double prod = coef0 * pn;
-                    ov = ov - prod;
+#pragma unroll 1
+        for (int jb = 0; jb < J; jb += JC) {
+        double2 pvr[JC], ob[JC];
+#pragma unroll
+        for (int j = 0; j < JC; j++) {
+            const int c0 = 2 * (tid + (jb + j) * T), cs = c0 < pitch ? c0 : 0;
+            pvr[j] = have_pivot ? *reinterpret_cast<const double2 *>(mrow + cs) : make_double2(0.0, 0.0);
+            ob[j] = *reinterpret_cast<const double2 *>(objA + cs);
+        }
+#pragma unroll
+        for (int j = 0; j < JC; j++) {
+            const int c0 = 2 * (tid + (jb + j) * T);
+            if (c0 >= pitch) continue;
+            double2 v = pvr[j];
+            v.x = fabs(v.x) > 1e-16 ? v.x / q : flushed;
+            v.y = fabs(v.y) > 1e-16 ? v.y / q : flushed;
+            *reinterpret_cast<double2 *>(prow + c0) = v;
+#pragma unroll
+            for (int k = 0; k < 2; k++) { // Dantzig pricing of the objective row as it is after this pivot (:71-79)
+                const int cc = c0 + k;
+                double ov = k ? ob[j].y : ob[j].x;
+                if (touched0) {
+                    const double pn = k ? v.y : v.x;
+                    if (cc == colx)
+                        ov = nq0;
+                    else if ((unsigned long long)__double_as_longlong(pn) != FLUSHED) {
+                        const double prod = coef0 * pn;
+                        ov = ov - prod;
+                    }
+                }
+                if (cc < n && ov > precision && ki_better(-ov, cc + 1, best.k, best.i)) {
+                    best.k = -ov;
+                    best.i = cc + 1;
                 }
             }
-            if (ov > precision && ki_better(-ov, cc + 1, best.k, best.i)) {
-                best.k = -ov;
-                best.i = cc + 1;
-            }
         }
-        best = block_argmin<T>(best, sk, si, slot);
+        }
+        best = block_argmin<T>(best, sk, si, slot); // (its barrier also publishes prow)
         slot ^= 1;
         la = best.i == INT_MAX ? 0 : best.i;
     }
@@ -257,14 +315,28 @@ __global__ __launch_bounds__(T) void wide_kernel(Desc d, int parity, int mode, i
         cofs[j] = c0 < pitch ? c0 : 0;
     }
     const int my_rows = b < h ? (h - 1 - b) / NB + 1 : 0;
+    double *colv = rhsv + rpw, *rin = colv + rpw; // (in place only) my rows' pivot-column entries and RHS as they are before this pivot
+    if constexpr (INPL) {
+        for (int i = tid; i < my_rows; i += T) {
+            const int r = b + NB * i;
+            colv[i] = matA[(size_t)r * pitch + colx];
+            rin[i] = rhsA[r];
+        }
+        __syncthreads();
+    }
     auto load_row = [&](double2 (&x)[J], double &cf, double &rr, int i) __attribute__((always_inline)) {
         const int r = b + NB * i;
         const int rs = r < h ? r : b; // in-bounds dummy past the end (b < h whenever this is reached)
-        cf = matA[(size_t)rs * pitch + colx];
-        rr = rhsA[rs];
+        if constexpr (INPL) {
+            cf = colv[r < h ? i : 0];
+            rr = rin[r < h ? i : 0];
+        } else {
+            cf = matA[(size_t)rs * pitch + colx];
+            rr = rhsA[rs];
+        }
         const double *mr = matA + (size_t)rs * pitch;
 #pragma unroll
-        for (int j = 0; j < J; j++) x[j] = *reinterpret_cast<const double2 *>(mr + cofs[j]);
+        for (int j = 0; j < J; j++) x[j] = ld_row(mr + cofs[j], NT);
     };
     auto process = [&](double2 (&x)[J], double cf, double rr, int i) __attribute__((always_inline)) {
         const int r = b + NB * i;
@@ -304,6 +376,10 @@ __global__ __launch_bounds__(T) void wide_kernel(Desc d, int parity, int mode, i
                 }
             }
             if (c0 == (lax & ~1)) lav[i] = (lax & 1) ? v.y : v.x; // the row's entry in the next entering column
+            if constexpr (INPL) {
+                if (r == 0) *reinterpret_cast<double2 *>(objB + c0) = v; // (workgroup 0: the next launch's replica, changed or not)
+                if (!(is_pivot_row || act)) continue;                     // in place: an untouched row stays where it is
+            }
             if (force & 64) {
                 st_row_nt(mr + c0, v);
             } else
@@ -317,7 +393,15 @@ __global__ __launch_bounds__(T) void wide_kernel(Desc d, int parity, int mode, i
     if (my_rows > 0) {
         double2 xa[J], xb[J];
         double cfa, cfb, rra, rrb;
-        load_row(xa, cfa, rra, 0);
+        const bool preloaded = INPL && mode == MODE_SHARD && !bootstrap; // (uniform)
+        if (preloaded) {
+#pragma unroll
+            for (int j = 0; j < J; j++) xa[j] = xa0[j];
+            cfa = colv[0];
+            rra = rin[0];
+        } else {
+            load_row(xa, cfa, rra, 0);
+        }
         for (int i = 0; i < my_rows; i += 2) {
             load_row(xb, cfb, rrb, i + 1);
             process(xa, cfa, rra, i);
@@ -367,7 +451,7 @@ __global__ __launch_bounds__(T) void wide_kernel(Desc d, int parity, int mode, i
     apply_swap();
     if (b == 0 && tid == 0 && !(force & 1)) {
         const bool counted = have_pivot && mode != MODE_APPLY;
-        write_state(RUNNING, phase, la, pbuf ^ 1, mbuf ^ 1, have_pivot ? 1 : 0, row, col,
+        write_state(RUNNING, phase, la, pbuf ^ 1, INPL ? mbuf : mbuf ^ 1, have_pivot ? 1 : 0, row, col,
                     (mode != MODE_APPLY && phase_switched) ? 0 : hist_len_in, counted ? iter + 1.0 : iter, NAN,
                     counted ? pivots_in + 1 : pivots_in);
     }

@@ -90,6 +90,22 @@ const WVariant kWide[] = {
     {1024, 2, wide_kernel<1024, 2>}, {1024, 4, wide_kernel<1024, 4>}, {1024, 8, wide_kernel<1024, 8>},
 };
 
+// ... and the in-place forms for row shards ([0] plain, [1] non-temporal row loads)
+struct WInplace {
+    int T, J; // the ping-pong variant it stands in for
+    KernelFn fn[2];
+    int launchT; // lanes of the in-place form (16 385-column rows: 512 x 16 units -- two 64-register row buffers fit the 256
+                 // registers of a 512-lane workgroup; <1024,8> has 128 and spills 17 of them)
+};
+const WInplace kWideInplace[] = {
+    {256, 1, {wide_kernel<256, 1, true, false>, wide_kernel<256, 1, true, true>}, 256},
+    {256, 2, {wide_kernel<256, 2, true, false>, wide_kernel<256, 2, true, true>}, 256},
+    {1024, 1, {wide_kernel<1024, 1, true, false>, wide_kernel<1024, 1, true, true>}, 1024},
+    {1024, 2, {wide_kernel<1024, 2, true, false>, wide_kernel<1024, 2, true, true>}, 1024},
+    {1024, 4, {wide_kernel<1024, 4, true, false>, wide_kernel<1024, 4, true, true>}, 1024},
+    {1024, 8, {wide_kernel<512, 16, true, false>, wide_kernel<512, 16, true, true>}, 512},
+};
+
 using ResidentFn = void (*)(Desc, int, int);
 struct RVariant {
     int T, J, R;
@@ -274,6 +290,8 @@ struct yalps_tableau {
     int32_t *perm_backup = nullptr; // basis before the resident launch in flight (restored if it fails)
     int32_t perm_len = 0; // entries of pos / var (width + GLOBAL height)
     Variant var{};
+    int wT_inplace = 0;
+    KernelFn wfn_inplace = nullptr; // row shard: wide_kernel<.., true, nt> for the MODE_SHARD launches (in place; d.obj holds the objective replicas)
     KernelFn wfn = nullptr; // wide_kernel variant used for FUSED / APPLY / SHARD launches when the tableau is
                             // too wide or too tall for pivot_kernel's register-resident batches
     size_t wshmem = 0;
@@ -310,6 +328,15 @@ void launch_one(yalps_tableau *t, int parity, int mode, int force, const double 
         t->wfn<<<dim3(grid), dim3(t->var.T), t->wshmem, t->ctx->stream>>>(t->d, parity, mode, force, gather);
     else
         t->var.fn<<<dim3(grid), dim3(t->var.T), 0, t->ctx->stream>>>(t->d, parity, mode, force, gather);
+}
+
+// the elimination step of a row shard (MODE_SHARD): in place where the shard has the kernel for it
+void launch_shard(yalps_tableau *t, const double *gathered) {
+    const int force = t->ctx->nt_stores ? 64 : 0;
+    if (t->wfn_inplace)
+        t->wfn_inplace<<<dim3(t->nb), dim3(t->wT_inplace), t->wshmem, t->ctx->stream>>>(t->d, t->shard_parity, MODE_SHARD, force, gathered);
+    else
+        launch_one(t, t->shard_parity, MODE_SHARD, force, gathered);
 }
 
 int launch_batch(yalps_tableau *t, int which) {
@@ -548,7 +575,7 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
     if (J >= 4 || (T == 1024 && J >= 2) || rows_per_block > pick->R || env_int("YALPS_HIP_WIDE", 0)) {
         for (const WVariant &v : kWide)
             if (v.T == T && v.J == J) t->wfn = v.fn;
-        t->wshmem = sizeof(double) * ((size_t)((n + 15) / 16 * 16 < 16 ? 16 : (n + 15) / 16 * 16) + 2 * (size_t)rows_per_block);
+        t->wshmem = sizeof(double) * ((size_t)((n + 15) / 16 * 16 < 16 ? 16 : (n + 15) / 16 * 16) + 4 * (size_t)rows_per_block); // (+ 2 per row: in-place shards)
         if (t->wshmem > 150 * 1024) t->generic = true; // (pivot row + per-row scalars exceed LDS)
         if (!t->generic && t->wshmem > 48 * 1024)
             if (int rc = allow_big_lds(ctx->device, reinterpret_cast<const void *>(t->wfn))) return rc;
@@ -737,7 +764,7 @@ void yalps_tableau_destroy(yalps_tableau *t) {
     void *bufs[] = {d.mat[0], d.mat[1], d.rhs[0], d.rhs[1], t->perm_block ? nullptr : d.pos, t->perm_block ? nullptr : d.var, t->perm_block,
                     t->ctl_block ? nullptr : d.st, t->ctl_block ? nullptr : d.cst, t->ctl_block, d.rc_rows[0], d.rc_rows[1], t->perm_backup,
                     d.rc_key[0], d.rc_key[1], d.gen_prow, d.gen_scal, d.part_ratio[0], d.part_ratio[1], d.part_rhs[0], d.part_rhs[1],
-                    t->hist[0], t->hist[1], t->cells, d.dbg};
+                    t->hist[0], t->hist[1], t->cells, d.dbg, d.obj[0]};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (t->host_state) (void)hipHostFree(t->host_state);
@@ -1607,6 +1634,24 @@ int32_t yalps_tableau_set_shard(yalps_tableau *t, int32_t rank, int32_t nranks, 
     t->perm_len = (int32_t)n;
     d.perm_len = t->perm_len;
     t->rvar.fn = nullptr; // a shard is driven step by step
+    // rows wide enough for wide_kernel are swept in place (YALPS_HIP_SHARD_INPLACE=0: ping-pong as in round 1)
+    t->wfn_inplace = nullptr;
+    if (t->wfn && env_int("YALPS_HIP_SHARD_INPLACE", 1)) {
+        const bool nt = env_int("YALPS_HIP_SHARD_NT", sizeof(double) * (size_t)d.pitch * (size_t)t->height > SWEEP_BEYOND_CACHE ? 1 : 0) != 0;
+        for (const WInplace &v : kWideInplace)
+            if (v.T == t->var.T && v.J == t->var.J) {
+                t->wfn_inplace = v.fn[nt ? 1 : 0];
+                t->wT_inplace = v.launchT;
+            }
+        if (t->wfn_inplace) {
+            if (t->wshmem > 48 * 1024)
+                if (int rc = allow_big_lds(t->ctx->device, reinterpret_cast<const void *>(t->wfn_inplace))) return rc;
+            if (!d.obj[0]) {
+                HIP_TRY(hipMalloc(&d.obj[0], sizeof(double) * 2 * (size_t)d.pitch));
+                d.obj[1] = d.obj[0] + d.pitch;
+            }
+        }
+    }
     // graphs captured for the unsharded tableau hold the old Desc
     for (int k = 0; k < 2; k++) {
         if (t->graph_exec[k]) (void)hipGraphExecDestroy(t->graph_exec[k]);
@@ -1627,6 +1672,8 @@ int32_t yalps_shard_begin(yalps_tableau *t, double precision, double maxPivots) 
     launch_one(t, 0, MODE_FUSED, 0); // bootstrap scan: emits this rank's first partials
     HIP_TRY(hipGetLastError());
     t->shard_parity = 1;
+    if (t->wfn_inplace) // (the scan left the tableau in buffer 1 and the partials in set 1: the first in-place launch reads replica 1)
+        HIP_TRY(hipMemcpyAsync(t->d.obj[1], t->d.mat[1], sizeof(double) * (size_t)t->d.pitch, hipMemcpyDeviceToDevice, t->ctx->stream));
     return 0;
 }
 
@@ -1644,7 +1691,7 @@ int32_t yalps_shard_select(yalps_tableau *t, double *send_dev) {
 
 int32_t yalps_shard_apply(yalps_tableau *t, const double *gathered_dev) {
     if (!t || !gathered_dev) return fail(YALPS_E_ARG, "yalps_shard_apply: bad argument");
-    launch_one(t, t->shard_parity, MODE_SHARD, t->ctx->nt_stores ? 64 : 0, gathered_dev);
+    launch_shard(t, gathered_dev);
     HIP_TRY(hipGetLastError());
     t->shard_parity ^= 1;
     return 0;
@@ -1826,7 +1873,7 @@ static int shard_step(yalps_tableau *t, yalps_comm *c, size_t slot) {
         HIP_TRY(hipMemcpyAsync(c->recv, c->pin + slot, sizeof(double) * slot * (size_t)c->nranks, hipMemcpyHostToDevice, s));
     }
     c->collectives++;
-    launch_one(t, t->shard_parity, MODE_SHARD, t->ctx->nt_stores ? 64 : 0, c->recv);
+    launch_shard(t, c->recv);
     t->shard_parity ^= 1;
     return 0;
 }
