@@ -1,0 +1,28 @@
+#!/bin/bash
+# Everything the round's tables and profiles/ are made from, in one GPU call (run from the repo root on the GPU box):
+#   tools/final_measurements.sh OUTDIR
+set -x
+out=${1:-gpurun_out/final}; mkdir -p $out; export TMPDIR=/tmp
+python3 bench.py > $out/bench.json 2> $out/bench.err
+rocprofv3 --kernel-trace --stats -d $out/stats --output-format csv -- python3 bench.py > $out/bench_prof.json 2> $out/bench_prof.err
+find $out/stats -name "*kernel_stats.csv" -exec cp {} $out/bench_kernel_stats.csv \; ; rm -rf $out/stats
+rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch --output-format csv -- python3 bench.py --steps 2 --warmup 0 --cpu-pivots 0 --sweep-launches 4 > /dev/null 2> $out/pmc_fetch.err
+python3 tools/pmc_summary.py $out/pmc_fetch FETCH_SIZE > $out/fetch_summary.json; rm -rf $out/pmc_fetch
+rocprofv3 --pmc WRITE_SIZE -d $out/pmc_write --output-format csv -- python3 bench.py --steps 2 --warmup 0 --cpu-pivots 0 --sweep-launches 4 > /dev/null 2> $out/pmc_write.err
+python3 tools/pmc_summary.py $out/pmc_write WRITE_SIZE > $out/write_summary.json; rm -rf $out/pmc_write
+python3 tools/resident_stages.py --size 2048 > $out/stages_2048.json 2> $out/stages.err
+YALPS_HIP_RESIDENT_GEN=1 python3 tools/resident_stages.py --size 2048 > $out/stages_2048_gen1.json 2>> $out/stages.err
+python3 tools/shape_sweep.py 32x32 128x128 256x256 512x512 1024x1024 1536x1536 2048x2048 2560x2560 3072x3072 3300x3000 4096x4096 5000x5000 512x4096 4096x512 1000x6000 10000x1000 11000x900 12000x1500 1024x8000 256x8192 8192x8192 1024x16384 1000x20000 > $out/shape_sweep.txt 2>&1
+python3 bench_bnb.py > $out/bnb.json 2> $out/bnb.err
+python3 bench_table.py > $out/table.json 2> $out/table.err
+python3 bench.py --workload sharded --size 16384 --gpus 1 --steps 2 --warmup 1 2> $out/shard16384.err | grep "^{" > $out/shard16384.json
+python3 bench.py --workload sharded --size 4096 --gpus 1 --steps 2 --warmup 1 2>/dev/null | grep "^{" > $out/shard4096.json
+rocprofv3 --kernel-trace --stats -d $out/shstats --output-format csv -- python3 bench.py --workload sharded --size 16384 --gpus 1 --steps 1 --warmup 1 > /dev/null 2>&1
+find $out/shstats -name "*kernel_stats.csv" -exec cp {} $out/shard16384_kernel_stats.csv \; ; rm -rf $out/shstats
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c -d $out/shpmc_$c --output-format csv -- python3 bench.py --workload sharded --size 16384 --gpus 1 --steps 1 --warmup 1 > /dev/null 2>&1
+  python3 tools/pmc_summary.py $out/shpmc_$c $c wide_kernel > $out/shard16384_$c.json; rm -rf $out/shpmc_$c
+done
+python3 tools/node_overhead.py "Monster 2" > $out/node_overhead.txt 2>&1
+python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --workload sharded --size 4096 --steps 1 --warmup 1 2> $out/rehearsal2.err | grep "^{" > $out/rehearsal2.json
+echo finished
