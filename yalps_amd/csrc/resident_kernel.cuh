@@ -422,7 +422,7 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
             }
             c.i = (int)(unsigned)f;
             c.k = rec.x;
-#ifndef YALPS_AB_RETURN_GUARD
+#ifdef YALPS_AB_POLL_GUARD
             // (never expected: a record that names no row of this tableau -- leave through the failure exit, with the error
             // word set, instead of indexing with it)
             if (c.i != INT_MAX && (unsigned)c.i >= (unsigned)h) {
@@ -455,7 +455,15 @@ __global__ __launch_bounds__(T) void resident_kernel(Desc d, int parity, int chu
             YSTAMP(14);
             continue;
         }
+#if defined(YALPS_AB_RETURN_GUARD) || defined(YALPS_AB_NOGUARD) || defined(YALPS_AB_POLL_GUARD)
         const int row = c.i, owner = row % NB;
+#else
+        // (never expected: a record that names no row of this tableau.  No exit of its own -- a `return` here, or a test in
+        // the poll loop, cost the tall variants 4-11 % per pivot through register allocation alone, same-box A/B --: the
+        // index is clamped, so that nothing is addressed with it, and the error word makes the host discard the launch)
+        const int row_in = c.i, row = (unsigned)row_in < (unsigned)h ? row_in : 0, owner = row % NB;
+        if (row != row_in && tid == 0) __hip_atomic_store(d.rc_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 #ifdef YALPS_AB_RETURN_GUARD
         if ((unsigned)row >= (unsigned)h) { // (never expected: a record that names no row of this tableau -- leave with the error
             if (tid == 0) __hip_atomic_store(d.rc_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // word set instead of indexing with it)

@@ -158,22 +158,28 @@ __global__ __launch_bounds__(T) void sweep_kernel(Desc d, int parity, int chunk)
         v = __builtin_amdgcn_readfirstlane(sh_rv);
         return sh_fail == 0;
     };
-    // Dantzig pricing (:71-79) of an objective-row slice held in registers (padding columns excluded) -> (la, entry)
-    auto price_regs = [&](const double2 (&o)[J], int &la_out, double &val_out) __attribute__((always_inline)) {
-        double best = precision;
-        int bi = INT_MAX;
+    // Dantzig pricing (:71-79) of an objective-row slice held in registers (padding columns excluded), units [u0, u0 + JN)
+    // at a time (a 16-unit row is priced in two halves: the whole row beside the sweep's buffers does not fit the registers):
+    // price_part accumulates a lane's best (value, which of its 2 J columns -- a compile-time constant per comparison: the
+    // column numbers themselves, 2 J loop invariants per lane, were hoisted out of the pivot loop into registers the sweep
+    // needs), price_finish reduces over the workgroup -> (la, entry)
+    constexpr int JP = J > 8 ? J / 2 : J;
+    auto price_part = [&](auto &o, int u0, double &best, int &bj) __attribute__((always_inline)) {
+        constexpr int JN = (int)(sizeof(o) / sizeof(o[0]));
 #pragma unroll
-        for (int j = 0; j < J; j++) {
-            const int c0 = 2 * (tid + j * T);
-            if (!(padmask & (1u << (2 * j))) && o[j].x > best) {
+        for (int j = 0; j < JN; j++) {
+            if (!(padmask & (1u << (2 * (u0 + j)))) && o[j].x > best) {
                 best = o[j].x;
-                bi = c0 + 1;
+                bj = 2 * (u0 + j);
             }
-            if (!(padmask & (1u << (2 * j + 1))) && o[j].y > best) {
+            if (!(padmask & (1u << (2 * (u0 + j) + 1))) && o[j].y > best) {
                 best = o[j].y;
-                bi = c0 + 2;
+                bj = 2 * (u0 + j) + 1;
             }
         }
+    };
+    auto price_finish = [&](double best, int bj, int &la_out, double &val_out) __attribute__((always_inline)) {
+        const int bi = bj < 0 ? INT_MAX : 2 * (tid + (bj >> 1) * T) + (bj & 1) + 1;
         KI v = {bi == INT_MAX ? INFINITY : -best, bi};
         v = block_argmin<T>(v, sk, si, slot);
         slot ^= 1;
@@ -220,11 +226,17 @@ __global__ __launch_bounds__(T) void sweep_kernel(Desc d, int parity, int chunk)
 
     // the entering column of the first pivot of this launch: workgroup 0 prices row 0 as loaded
     if (b == 0) {
-        double2 o[J];
         const __amdgpu_buffer_rsrc_t r0 = rsrc_of(mat);
+        double best = precision;
+        int bj = -1;
 #pragma unroll
-        for (int j = 0; j < J; j++) o[j] = row_ld16<AUX_PLAIN>(r0, lane_off + 16 * T * j, 0);
-        price_regs(o, la, la_val);
+        for (int u0 = 0; u0 < J; u0 += JP) {
+            double2 o[JP];
+#pragma unroll
+            for (int j = 0; j < JP; j++) o[j] = row_ld16<AUX_PLAIN>(r0, lane_off + 16 * T * (u0 + j), 0);
+            price_part(o, u0, best, bj);
+        }
+        price_finish(best, bj, la, la_val);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tid == 0) put_rec(sync->rec_la[1], la_val, 1u, la);
     }
@@ -455,68 +467,81 @@ __global__ __launch_bounds__(T) void sweep_kernel(Desc d, int parity, int chunk)
         iter += 1.0;
         pivots += 1;
         done += 1;
-        // one row of mine, as pivot() leaves it, from its loaded slice; the new slice stays in x
-        auto finish = [&](int i, double2 (&x)[J]) __attribute__((always_inline)) {
+        // units [u0, u0 + JN) of one row of mine, as pivot() leaves it, from its loaded slice; the new slice stays in x
+        // (u0 is a constant at every call site: the offsets fold)
+        auto finish_u = [&](int i, int u0, auto &x) __attribute__((always_inline)) {
+            constexpr int JN = (int)(sizeof(x) / sizeof(x[0]));
             const double coef = uniform_f64(colv[i]);
             const __amdgpu_buffer_rsrc_t rs = rsrc_of(mat + (size_t)(b + NB * i) * pitch);
             if (i == lslot) {
 #pragma unroll
-                for (int j = 0; j < J; j++) {
-                    const double2 pn = *reinterpret_cast<const double2 *>(prow + 2 * (tid + j * T));
+                for (int j = 0; j < JN; j++) {
+                    const double2 pn = *reinterpret_cast<const double2 *>(prow + 2 * (tid + (u0 + j) * T));
                     x[j].x = (unsigned long long)__double_as_longlong(pn.x) != FLUSHED ? pn.x : 0.0;
                     x[j].y = (unsigned long long)__double_as_longlong(pn.y) != FLUSHED ? pn.y : 0.0;
                 }
             } else if (fast) {
 #pragma unroll
-                for (int j = 0; j < J; j++) {
-                    const double2 pn = *reinterpret_cast<const double2 *>(prow + 2 * (tid + j * T));
+                for (int j = 0; j < JN; j++) {
+                    const double2 pn = *reinterpret_cast<const double2 *>(prow + 2 * (tid + (u0 + j) * T));
                     const double px = coef * pn.x, py = coef * pn.y;
                     x[j].x = x[j].x - px;
                     x[j].y = x[j].y - py;
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < J; j++) {
-                    const double2 pn = *reinterpret_cast<const double2 *>(prow + 2 * (tid + j * T));
+                for (int j = 0; j < JN; j++) {
+                    const double2 pn = *reinterpret_cast<const double2 *>(prow + 2 * (tid + (u0 + j) * T));
                     const double px = coef * pn.x, py = coef * pn.y;
                     const double nx = x[j].x - px, ny = x[j].y - py;
                     x[j].x = (unsigned long long)__double_as_longlong(pn.x) != FLUSHED ? nx : x[j].x;
                     x[j].y = (unsigned long long)__double_as_longlong(pn.y) != FLUSHED ? ny : x[j].y;
+                    __builtin_amdgcn_sched_barrier(0); // (unit by unit: interleaved, the differences waiting for their selects spilled)
                 }
             }
             const double patch = uniform_f64(nqv[i]); // the pivot column itself (:25, :36)
 #pragma unroll
-            for (int j = 0; j < J; j++) {
-                const int c0 = 2 * (tid + j * T);
+            for (int j = 0; j < JN; j++) {
+                const int c0 = 2 * (tid + (u0 + j) * T);
                 if (c0 == (colx & ~1)) {
                     if (colx & 1)
                         x[j].y = patch;
                     else
                         x[j].x = patch;
                 }
-                row_st16<NT ? AUX_NT : AUX_PLAIN>(rs, lane_off + 16 * T * j, 0, x[j]);
+                row_st16<NT ? AUX_NT : AUX_PLAIN>(rs, lane_off + 16 * T * (u0 + j), 0, x[j]);
             }
         };
-        auto load = [&](int i, double2 (&x)[J]) __attribute__((always_inline)) {
+        auto load_u = [&](int i, int u0, auto &x) __attribute__((always_inline)) {
+            constexpr int JN = (int)(sizeof(x) / sizeof(x[0]));
             const __amdgpu_buffer_rsrc_t rs = rsrc_of(mat + (size_t)(b + NB * i) * pitch);
 #pragma unroll
-            for (int j = 0; j < J; j++) x[j] = row_ld16<NT ? AUX_NT : AUX_PLAIN>(rs, lane_off + 16 * T * j, 0);
+            for (int j = 0; j < JN; j++) x[j] = row_ld16<NT ? AUX_NT : AUX_PLAIN>(rs, lane_off + 16 * T * (u0 + j), 0);
         };
+        auto finish = [&](int i, double2 (&x)[J]) __attribute__((always_inline)) { finish_u(i, 0, x); };
+        auto load = [&](int i, double2 (&x)[J]) __attribute__((always_inline)) { load_u(i, 0, x); };
         int k0 = 0;
         if (b == 0) {
             // row 0 first: priced from the registers it was just computed in, the next entering column leaves at once
-            double2 o[J];
-            if (ntouch > 0 && __builtin_amdgcn_readfirstlane(tlist[0]) == 0) {
-                load(0, o);
-                finish(0, o);
-                k0 = 1;
-            } else { // (the objective row's pivot-column entry was within 1e-16: row 0 is unchanged)
+            const bool touched0 = ntouch > 0 && __builtin_amdgcn_readfirstlane(tlist[0]) == 0; // (uniform)
+            double best = precision;
+            int bj = -1;
 #pragma unroll
-                for (int j = 0; j < J; j++) o[j] = row_ld16<AUX_SC1>(rsrc_of(mat), lane_off + 16 * T * j, 0);
+            for (int u0 = 0; u0 < J; u0 += JP) {
+                double2 o[JP];
+                if (touched0) {
+                    load_u(0, u0, o);
+                    finish_u(0, u0, o);
+                } else { // (the objective row's pivot-column entry was within 1e-16: row 0 is unchanged)
+#pragma unroll
+                    for (int j = 0; j < JP; j++) o[j] = row_ld16<AUX_SC1>(rsrc_of(mat), lane_off + 16 * T * (u0 + j), 0);
+                }
+                price_part(o, u0, best, bj);
             }
+            if (touched0) k0 = 1;
             int nla;
             double nval;
-            price_regs(o, nla, nval);
+            price_finish(best, bj, nla, nval);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (tid == 0) put_rec(sync->rec_la[(epoch + 1) & 1], nval, epoch + 1, nla);
             la = nla;
@@ -524,21 +549,35 @@ __global__ __launch_bounds__(T) void sweep_kernel(Desc d, int parity, int chunk)
         }
         // ---------------- the sweep: D rows in flight per lane -----------------------------------------------------------
         if constexpr (D == 2) {
-            for (int k = k0; k < ntouch; k += 2) {
-                // (slot numbers in scalar registers: a row's base is then a scalar address)
-                const int i0 = __builtin_amdgcn_readfirstlane(tlist[k]), i1 = __builtin_amdgcn_readfirstlane(tlist[k + 1 < ntouch ? k + 1 : k]);
+            // two row buffers taking turns: the next row's loads are in flight while this one is eliminated and stored
+            // (slot numbers in scalar registers: a row's base is then a scalar address)
+            if (k0 < ntouch) {
                 double2 xa[J], xb[J];
-                load(i0, xa);
-                load(i1, xb);
-                finish(i0, xa);
-                if (k + 1 < ntouch) finish(i1, xb);
+                load(__builtin_amdgcn_readfirstlane(tlist[k0]), xa);
+                for (int k = k0; k < ntouch; k += 2) {
+                    const int i0 = __builtin_amdgcn_readfirstlane(tlist[k]);
+                    const int i1 = __builtin_amdgcn_readfirstlane(tlist[k + 1 < ntouch ? k + 1 : k]);
+                    const int i2 = __builtin_amdgcn_readfirstlane(tlist[k + 2 < ntouch ? k + 2 : k]);
+                    if (k + 1 < ntouch) load(i1, xb);
+                    finish(i0, xa);
+                    if (k + 2 < ntouch) load(i2, xa);
+                    if (k + 1 < ntouch) finish(i1, xb);
+                }
             }
         } else {
-            for (int k = k0; k < ntouch; k++) {
-                const int i0 = __builtin_amdgcn_readfirstlane(tlist[k]);
-                double2 xa[J];
-                load(i0, xa);
-                finish(i0, xa);
+            // 16-unit rows: two HALF-row buffers taking turns the same way (two whole rows do not fit the registers)
+            constexpr int JH = J / 2;
+            if (k0 < ntouch) {
+                double2 xa[JH], xb[JH];
+                load_u(__builtin_amdgcn_readfirstlane(tlist[k0]), 0, xa);
+                for (int k = k0; k < ntouch; k++) {
+                    const int i0 = __builtin_amdgcn_readfirstlane(tlist[k]);
+                    const int i1 = __builtin_amdgcn_readfirstlane(tlist[k + 1 < ntouch ? k + 1 : k]);
+                    load_u(i0, JH, xb);
+                    finish_u(i0, 0, xa);
+                    if (k + 1 < ntouch) load_u(i1, 0, xa);
+                    finish_u(i0, JH, xb);
+                }
             }
         }
         if (b == 0 && tid == 0) { // basis bookkeeping, :7-12
