@@ -23,6 +23,18 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c -d $out/shpmc_$c --output-format csv -- python3 bench.py --workload sharded --size 16384 --gpus 1 --steps 1 --warmup 1 > /dev/null 2>&1
   python3 tools/pmc_summary.py $out/shpmc_$c $c wide_kernel > $out/shard16384_$c.json; rm -rf $out/shpmc_$c
 done
+# sweep_kernel on the HBM-bound shapes: rocprof kernel stats + PMC passes of one bounded launch each
+for shape in "16384 0 300" "8192 0 800" "16384 1024 2000" "16384 4096 600"; do
+  set -- $shape; tag=$( [ "$2" = 0 ] && echo $(( $1 + 1 ))x$(( $1 + 1 )) || echo $(( $2 + 1 ))x$(( $1 + 1 )) )
+  rows=$( [ "$2" = 0 ] || echo "--rows $2" )
+  rocprofv3 --kernel-trace --stats -d $out/sw_$tag --output-format csv -- python3 tools/profile_solve.py --size $1 $rows --pivots $3 > $out/sweep_$tag.json 2> /dev/null
+  find $out/sw_$tag -name "*kernel_stats.csv" -exec cp {} $out/sweep_${tag}_kernel_stats.csv \; ; rm -rf $out/sw_$tag
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $c -d $out/swpmc --output-format csv -- python3 tools/profile_solve.py --size $1 $rows --pivots $3 > /dev/null 2>&1
+    python3 tools/pmc_summary.py $out/swpmc $c sweep_kernel > $out/sweep_${tag}_$c.json; rm -rf $out/swpmc
+  done
+done
+python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 2 --steps 3 --warmup 1 2> $out/rehearsal_replicas2.err | grep "^{" > $out/rehearsal_replicas2.json
 python3 tools/node_overhead.py "Monster 2" > $out/node_overhead.txt 2>&1
 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --workload sharded --size 4096 --steps 1 --warmup 1 2> $out/rehearsal2.err | grep "^{" > $out/rehearsal2.json
 echo finished
