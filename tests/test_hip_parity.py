@@ -464,12 +464,17 @@ def test_resident_lds_rows_whole_solves(nat, ctx, oracle, monkeypatch, variant, 
     assert np.array_equal(got.view(np.int64), ref.view(np.int64))
 
 
-# ---- persistent in-place kernel (stream_kernel) for tableaux beyond the on-chip size ---------------
-@pytest.mark.parametrize("M,N,pivots", [(2800, 3300, 120), (1400, 8000, 80), (12000, 1500, 60), (11000, 900, 60), (12000, 400, 60)])
-def test_inplace_path_matches_restatement(nat, ctx, monkeypatch, M, N, pivots):
-    """Dense tableaux that do not fit the register-resident kernel: `pivots` pivots (phase 1 first)
-    through stream_kernel, against the pinned numpy restatement, bit for bit."""
+# ---- persistent in-place kernels (stream2_kernel: two pivots per sweep; stream_kernel) for tableaux beyond the on-chip size ----
+@pytest.mark.parametrize("delay", ["1", "0"], ids=["stream2", "stream"])
+@pytest.mark.parametrize("M,N,pivots", [(2800, 3300, 120), (1400, 8000, 81), (12000, 1500, 60), (11000, 900, 61), (12000, 400, 60),
+                                        (2800, 3300, 1), (1400, 8000, 2), (2800, 3300, 3)])
+def test_inplace_path_matches_restatement(nat, ctx, monkeypatch, M, N, pivots, delay):
+    """Dense tableaux that do not fit the register-resident kernel: `pivots` pivots (phase 1 first) through stream2_kernel
+    (the rows get two pivots' eliminations per sweep; odd budgets leave through the one-pivot flush) and through
+    stream_kernel, against the pinned numpy restatement, bit for bit."""
     from tests import _np_simplex as NP
+    monkeypatch.setenv("YALPS_HIP_DELAY", delay)
+    monkeypatch.setenv("YALPS_HIP_SWEEP", "0")  # (the 8001-column shape: stream_kernel<1024,4>, not sweep_kernel)
     monkeypatch.setenv("YALPS_HIP_LDS_ROWS", "0")  # (two of the shapes would fit with rows parked in LDS)
     w, h = N + 1, M + 1
     m = nat.dense_lp(M, N, 11)
@@ -486,7 +491,7 @@ def test_inplace_path_matches_restatement(nat, ctx, monkeypatch, M, N, pivots):
         got, gpos, gvar = t.download()
     finally:
         t.close()
-    assert info["last_path"] == "inplace" and info["inplace"].startswith("stream_kernel"), info
+    assert info["last_path"] == "inplace" and info["inplace"].startswith("stream2_kernel" if delay == "1" else "stream_kernel"), info
     assert (status, npiv) == (est, epiv) and G.same_number(result, eres)
     assert np.array_equal(gpos, rpos) and np.array_equal(gvar, rvar)
     assert np.array_equal(got.view(np.int64), ref.view(np.int64))
@@ -603,7 +608,7 @@ def test_two_tableaux_share_a_kernel_with_different_lds_needs(nat, ctx):
             t, m, w, h, pos = tabs[k]
             t.upload(m, h, pos, pos.copy())
             st, res, piv, _ = t.solve(max_pivots=20)
-            assert t.info()["last_path"] == "inplace" and t.info()["inplace"] == "stream_kernel<1024,4>", t.info()
+            assert t.info()["last_path"] == "inplace" and t.info()["inplace"] == "stream2_kernel<1024,4>", t.info()
             runs.append((k, st, res, piv, t.download()))
     finally:
         for t, *_ in tabs:
@@ -644,15 +649,17 @@ def test_inplace_fallback_restores_the_tableau(oracle, lds_rows, path):
 TALL = [("inplace", "0"), ("resident", "1")]  # 11001 rows: stream_kernel, or resident_kernel<512,1,38> + 5 rows per workgroup in LDS
 
 
-@pytest.mark.parametrize("path,lds_rows", TALL)
+@pytest.mark.parametrize("path,lds_rows,delay", [("inplace", "0", "1"), ("inplace", "0", "0"), ("resident", "1", "1")],
+                         ids=["stream2", "stream", "resident-lds"])
 @pytest.mark.parametrize("kind", ["unbounded", "infeasible", "optimal", "optimal-degenerate"])
-def test_inplace_path_terminal_statuses(nat, ctx, monkeypatch, kind, path, lds_rows):
+def test_inplace_path_terminal_statuses(nat, ctx, monkeypatch, kind, path, lds_rows, delay):
     """The persistent kernels' exits other than the pivot budget, on a tall narrow LP (11001 x 61: beyond the register
-    variants) solved to the end through stream_kernel and through the resident kernel with LDS rows: unbounded after
-    124 pivots (result = the column), infeasible after 41 phase-1 pivots, optimal, and optimal with every 10th
-    right-hand side zero (ties, ratios <= precision)."""
+    variants) solved to the end through stream2_kernel (which may leave with a pivot still pending: the flush), through
+    stream_kernel and through the resident kernel with LDS rows: unbounded after 124 pivots (result = the column),
+    infeasible after 41 phase-1 pivots, optimal, and optimal with every 10th right-hand side zero (ties, ratios <= precision)."""
     from tests import _np_simplex as NP
     monkeypatch.setenv("YALPS_HIP_LDS_ROWS", lds_rows)
+    monkeypatch.setenv("YALPS_HIP_DELAY", delay)
     M, N = 11000, 60
     w, h = N + 1, M + 1
     m = nat.dense_lp(M, N, 21)
@@ -849,9 +856,13 @@ SWEEP = [  # M, N, pivots, env, expected kernel, checkCycles
     (600, 16000, 70, {}, "sweep_kernel<512,16>", False),
     (300, 9000, 60, {"YALPS_HIP_SWEEP_NT": "1"}, "sweep_kernel<512,16,nt>", False),
     (2100, 12345, 50, {}, "sweep_kernel<512,16>", False),
-    (1400, 8000, 80, {"YALPS_HIP_SWEEP": "2"}, "sweep_kernel<512,8>", False),
-    (2500, 5000, 60, {"YALPS_HIP_SWEEP": "2", "YALPS_HIP_SWEEP_NT": "1"}, "sweep_kernel<512,8,nt>", False),
+    (1400, 8000, 80, {"YALPS_HIP_SWEEP": "2", "YALPS_HIP_DELAY": "0"}, "sweep_kernel<512,8>", False),
+    (2500, 5000, 60, {"YALPS_HIP_SWEEP": "2", "YALPS_HIP_SWEEP_NT": "1", "YALPS_HIP_DELAY": "0"}, "sweep_kernel<512,8,nt>", False),
     (900, 7000, 60, {"YALPS_HIP_SWEEP": "2"}, "sweep_kernel<512,8>", True),
+    # stream2_kernel (two pivots per sweep) with the same awkward data; its non-temporal forms; odd budgets
+    (1400, 8000, 81, {"YALPS_HIP_DELAY_NT": "1"}, "stream2_kernel<1024,4,nt>", False),
+    (4300, 4000, 61, {"YALPS_HIP_DELAY_NT": "1"}, "stream2_kernel<1024,2,nt>", False),
+    (900, 7000, 60, {}, "stream2_kernel<1024,4>", False),
 ]
 
 

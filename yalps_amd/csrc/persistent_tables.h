@@ -31,3 +31,5 @@ int yalps_sweep_sync_bytes(); // sizeof(SweepSync): its records at the head of t
 // stream_kernel<T, J, false> / <T, J, true> (with hasCycle): persistent, in place
 PersistentTable yalps_stream_table();
 PersistentTable yalps_stream_check_table();
+// stream2_kernel<T, J, NT>: the same with the row updates delayed by one pivot -- two pivots per sweep (stream2_kernel.cuh); R = NT
+PersistentTable yalps_stream2_table();

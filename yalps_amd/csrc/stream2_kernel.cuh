@@ -1,0 +1,493 @@
+// stream2_kernel.cuh -- persistent in-place pivot loop with the row updates DELAYED by one pivot (two pivots per sweep)
+// Part of libyalps_hip.so; included by persistent_stream2.hip inside its unnamed namespace (gfx950 only).
+#pragma once
+
+// ------------------------------------------------------------------------------------------
+// stream2_kernel<T lanes, J units per lane per row, NT>: stream_kernel's protocol and data placement (rows in HBM /
+// Infinity Cache, updated in place by the workgroup that owns them; objective replica in registers; one candidate
+// exchange per pivot with the candidate rows published write-through) -- but a pivot's elimination (src/simplex.ts:27-38)
+// is not carried out on the rows when the pivot is decided.  It stays PENDING: its normalised pivot row stays in LDS, my
+// rows' pivot-column entries stay in LDS, and everything the NEXT decision needs is computed from scalars, as stream_kernel
+// already does for its look-ahead:
+//   * my rows' right-hand sides (:33 at column 0) and my objective replica are updated at once;
+//   * my rows' entries of any one column c "as of now" = the entry in memory, run through the pending pivots' scalar form
+//     x - coef * p[c] (with the 1e-16 flush, the -coef/quotient and 1/quotient patches of :14-25, :36): one gather, a few
+//     flops per row;
+//   * my candidate row for the next exchange is loaded, run through the pending pivots in registers and published -- it
+//     alone, not stored.
+// When TWO pivots are pending (or the loop stops) every touched row is streamed ONCE and gets both eliminations in
+// registers, each with its own separately rounded multiply and subtract in the reference's order: bit for bit what two
+// sweeps leave, at half the traffic.  The exchange is unchanged: one per pivot.
+// Per pivot an element costs 8 instead of 16 bytes of HBM traffic: where stream_kernel / sweep_kernel sit on the memory
+// roofline (4097 x 4097: 38 us per pivot out of the Infinity Cache, 8193 x 8193: 183 us out of HBM) this one moves half.
+// No checkCycles (those solves keep stream_kernel).  NT: non-temporal row traffic (tableaux beyond the Infinity Cache).
+// ------------------------------------------------------------------------------------------
+template <int T, int J, bool NT>
+__global__ __launch_bounds__(T) void stream2_kernel(Desc d, int parity, int chunk) {
+    __shared__ double sk[2][16];
+    __shared__ int si[2][16];
+    __shared__ double sh_q, sh_c0; // quotient; objective-row entry of the pivot column
+    __shared__ int sh_fail, sh_nt;
+    extern __shared__ double sm_dyn[]; // prow[2][pitch], colv[2][rpw], lav[rpw], rhsv[rpw], tlist[rpw] (int)
+
+    const int tid = threadIdx.x, NB = d.nb, b = blockIdx.x;
+    const YState *Sin = d.st + parity;
+    YState *Sout = d.st + (parity ^ 1);
+    const YConst *C = d.cst;
+    if (Sin->status != RUNNING) {
+        if (b == 0 && tid == 0) state_copy(Sout, Sin);
+        return;
+    }
+    const int h = C->height, n = d.n, pitch = d.pitch, w = d.w;
+    const double precision = C->precision, max_pivots = C->max_pivots;
+    const int mbuf = Sin->mbuf;
+    double *mat = d.mat[mbuf];
+    double *rhs = d.rhs[mbuf];
+    int phase = Sin->phase;
+    double iter = Sin->iter;
+    int64_t pivots = Sin->pivots;
+    const int64_t hist_len = Sin->hist_len;
+    int slot = 0;
+    const int rpw = (d.hcap + NB - 1) / NB;
+    const int my_rows = b < h ? (h - 1 - b) / NB + 1 : 0;
+    double *prow0 = sm_dyn, *prow1 = prow0 + pitch, *colv0 = prow1 + pitch, *colv1 = colv0 + rpw, *lav = colv1 + rpw, *rhsv = lav + rpw;
+    int *tlist = reinterpret_cast<int *>(rhsv + rpw);
+    const double flushed = __longlong_as_double((long long)FLUSHED);
+
+    int cofs[J];
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+        const int c0 = 2 * (tid + j * T);
+        cofs[j] = c0 < pitch ? c0 : 0;
+    }
+    // ---- my replica of the objective row (registers), my rows' RHS (LDS) ----
+    double2 o[J];
+#pragma unroll
+    for (int j = 0; j < J; j++) o[j] = *reinterpret_cast<const double2 *>(mat + cofs[j]);
+    for (int i = tid; i < my_rows; i += T) rhsv[i] = rhs[b + NB * i];
+    if (tid == 0) sh_fail = 0;
+    __syncthreads();
+
+    // ---- the pending pivots (at most two; [0] is the older): scalars in registers, rows and columns in LDS ----
+    int npend = 0;
+    int lslot0 = -1, lslot1 = -1, colx0 = 0, colx1 = 0;
+    double q0 = 1.0, q1 = 1.0, invq0 = 1.0, invq1 = 1.0;
+    // entry (my row slot i, mat column c) after ONE pending pivot, given the entry before it (:14-25, :31-36 for one element)
+    auto after1 = [&](const double *prowp, const double *colvp, int lslotp, int colxp, double qp, double invqp, int i, double v, int c)
+                      __attribute__((always_inline)) {
+        const double p = prowp[c];
+        const bool pnz = (unsigned long long)__double_as_longlong(p) != FLUSHED;
+        const double coef = colvp[i];
+        if (i == lslotp) return c == colxp ? invqp : (pnz ? p : 0.0);
+        if (fabs(coef) > 1e-16) {
+            if (c == colxp) return -coef / qp;
+            if (pnz) {
+                const double prod = coef * p;
+                return v - prod;
+            }
+        }
+        return v;
+    };
+    // my rows' entries of mat column c as they are NOW (memory + the pending pivots) -> out[]; one barrier
+    auto column_now = [&](int c, double *out) __attribute__((always_inline)) {
+        for (int i = tid; i < my_rows; i += T) {
+            double v = ld_sc1(mat + (size_t)(b + NB * i) * pitch + c);
+            if (npend >= 1) v = after1(prow0, colv0, lslot0, colx0, q0, invq0, i, v, c);
+            if (npend >= 2) v = after1(prow1, colv1, lslot1, colx1, q1, invq1, i, v, c);
+            out[i] = v;
+        }
+        __syncthreads();
+    };
+    // one pending pivot applied to a whole row slice held in registers (the same arithmetic as stream_kernel's finish_row)
+    auto apply_row = [&](const double *prowp, const double *colvp, int lslotp, int colxp, double qp, double invqp, int i, double2 (&x)[J])
+                         __attribute__((always_inline)) {
+        const double coef = colvp[i];
+        const bool is_piv = i == lslotp;
+        const bool act = !is_piv && fabs(coef) > 1e-16; // :31
+        if (!is_piv && !act) return;
+        const double patch = is_piv ? invqp : -coef / qp; // :25 / :36
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            const int c0 = 2 * (tid + j * T);
+            if (c0 >= pitch) continue;
+            const double2 pn = *reinterpret_cast<const double2 *>(prowp + c0);
+            const bool f0 = (unsigned long long)__double_as_longlong(pn.x) != FLUSHED;
+            const bool f1 = (unsigned long long)__double_as_longlong(pn.y) != FLUSHED;
+            if (is_piv) {
+                x[j].x = f0 ? pn.x : 0.0;
+                x[j].y = f1 ? pn.y : 0.0;
+            } else {
+                const double px = coef * pn.x, py = coef * pn.y;
+                const double nx = x[j].x - px, ny = x[j].y - py;
+                x[j].x = f0 ? nx : x[j].x;
+                x[j].y = f1 ? ny : x[j].y;
+            }
+            if (c0 == (colxp & ~1)) {
+                if (colxp & 1)
+                    x[j].y = patch;
+                else
+                    x[j].x = patch;
+            }
+        }
+    };
+    auto apply_pending = [&](int i, double2 (&x)[J]) __attribute__((always_inline)) {
+        if (npend >= 1) apply_row(prow0, colv0, lslot0, colx0, q0, invq0, i, x);
+        if (npend >= 2) apply_row(prow1, colv1, lslot1, colx1, q1, invq1, i, x);
+    };
+    auto load_row = [&](int i, double2 (&x)[J]) __attribute__((always_inline)) {
+        const double *m = mat + (size_t)(b + NB * i) * pitch;
+#pragma unroll
+        for (int j = 0; j < J; j++) x[j] = ld_row(m + cofs[j], NT);
+    };
+    auto store_row = [&](int i, const double2 (&x)[J]) __attribute__((always_inline)) {
+        double *m = mat + (size_t)(b + NB * i) * pitch;
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            const int c0 = 2 * (tid + j * T);
+            if (c0 >= pitch) continue;
+            if (NT)
+                st_row_nt(m + c0, x[j]);
+            else
+                *reinterpret_cast<double2 *>(m + c0) = x[j];
+        }
+    };
+    // every touched row streamed once, all pending eliminations in registers; afterwards nothing is pending
+    auto flush_pending = [&]() __attribute__((always_inline)) {
+        if (npend == 0) return; // (uniform)
+        if (tid < 64) { // compact list of my touched rows (wave 0)
+            int cnt = 0;
+            for (int base = 0; base < my_rows; base += 64) {
+                const int i = base + tid;
+                bool t = false;
+                if (i < my_rows) {
+                    t = i == lslot0 || fabs(colv0[i]) > 1e-16;
+                    if (npend >= 2) t = t || i == lslot1 || fabs(colv1[i]) > 1e-16;
+                }
+                const unsigned long long m = __ballot(t);
+                if (t) tlist[cnt + __popcll(m & ((1ull << tid) - 1ull))] = i;
+                cnt += __popcll(m);
+            }
+            if (tid == 0) sh_nt = cnt;
+        }
+        __syncthreads();
+        const int nt = sh_nt;
+        if constexpr (J <= 2) { // two row buffers taking turns
+            if (nt > 0) {
+                double2 xa[J], xb[J];
+                load_row(tlist[0], xa);
+                for (int k = 0; k < nt; k += 2) {
+                    const int i0 = tlist[k], i1 = tlist[k + 1 < nt ? k + 1 : k], i2 = tlist[k + 2 < nt ? k + 2 : k];
+                    if (k + 1 < nt) load_row(i1, xb);
+                    apply_pending(i0, xa);
+                    store_row(i0, xa);
+                    if (k + 2 < nt) load_row(i2, xa);
+                    if (k + 1 < nt) {
+                        apply_pending(i1, xb);
+                        store_row(i1, xb);
+                    }
+                }
+            }
+        } else {
+            for (int k = 0; k < nt; k++) {
+                const int i0 = tlist[k];
+                double2 xa[J];
+                load_row(i0, xa);
+                apply_pending(i0, xa);
+                store_row(i0, xa);
+            }
+        }
+        npend = 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads(); // my rows are complete in memory (and the LDS arrays free) before anything reads them again
+    };
+
+    int la = 0; // entering column of the NEXT pivot (phase 2), priced on my objective replica
+    auto price = [&]() __attribute__((always_inline)) { // src/simplex.ts:71-79
+        KI best = {INFINITY, INT_MAX};
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            const int c0 = 2 * (tid + j * T);
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const double ov = elem(o[j], k);
+                if (c0 + k < n && ov > precision && ki_better(-ov, c0 + k + 1, best.k, best.i)) {
+                    best.k = -ov;
+                    best.i = c0 + k + 1;
+                }
+            }
+        }
+        best = block_argmin<T>(best, sk, si, slot);
+        slot ^= 1;
+        la = best.i == INT_MAX ? 0 : best.i;
+    };
+    // my candidate of the given kind (1 = most negative RHS, 2 = min ratio against lav[]); uniform result
+    auto candidate = [&](int kind) __attribute__((always_inline)) {
+        KI c = {INFINITY, INT_MAX};
+        for (int i = tid; i < my_rows; i += T) {
+            const int r = b + NB * i;
+            if (r < 1) continue;
+            const double my_rhs = rhsv[i];
+            if (kind == 1) {
+                if (my_rhs < -precision && ki_better(my_rhs, r, c.k, c.i)) {
+                    c.k = my_rhs;
+                    c.i = r;
+                }
+            } else if (la > 0) {
+                const double value = lav[i];
+                if (value > precision) {
+                    const double ratio = my_rhs / value;
+                    if (ratio < INFINITY) {
+                        const double key = (ratio <= precision) ? -INFINITY : ratio;
+                        if (ki_better(key, r, c.k, c.i)) {
+                            c.k = key;
+                            c.i = r;
+                        }
+                    }
+                }
+            }
+        }
+        c = block_argmin<T>(c, sk, si, slot);
+        slot ^= 1;
+        return c;
+    };
+    unsigned epoch = 0;
+    // my candidate and its row AS IT IS NOW (memory + pending pivots, in registers; not stored): write-through, drained, flag
+    auto publish = [&](KI cand) __attribute__((always_inline)) {
+        epoch++;
+        const int par = epoch & 1, cg = cand.i == INT_MAX ? 0 : cand.i / NB;
+        if (my_rows > 0) {
+            double2 x[J];
+            const double *m = mat + (size_t)(b + NB * cg) * pitch;
+#pragma unroll
+            for (int j = 0; j < J; j++) x[j] = *reinterpret_cast<const double2 *>(m + cofs[j]);
+            apply_pending(cg, x);
+            double *dst = d.rc_rows[par] + (size_t)b * pitch;
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                const int c0 = 2 * (tid + j * T);
+                if (c0 < pitch) st16_sc1(dst + c0, x[j]);
+            }
+        }
+        if (tid == 0) st_sc1(d.rc_key[par] + b, rhsv[cg]); // the candidate row's RHS entry
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains ...
+        __syncthreads();                                    // ... before ONE lane raises the flag:
+        if (tid == 0) // ONE 16-byte record {candidate key, epoch << 32 | row}, one store, polled with one 16-byte load
+            st16_sc1(reinterpret_cast<double *>(d.rc_flag[par] + 2 * b),
+                     make_double2(cand.k, __longlong_as_double((long long)(((unsigned long long)epoch << 32) | (unsigned)cand.i))));
+    };
+    int done = 0, term = RUNNING;
+    double term_result = NAN;
+    bool stop = false;
+    auto check = [&]() __attribute__((always_inline)) { // src/simplex.ts:69,109 and :80
+        if (done == chunk) {
+            stop = true;
+        } else if (!(iter < max_pivots)) {
+            term = YALPS_CYCLED;
+            stop = true;
+        } else if (phase == 2 && la == 0) {
+            term = YALPS_OPTIMAL;
+            stop = true;
+        }
+    };
+
+    // first round: candidates from the tableau as loaded
+    price();
+    if (la > 0)
+        column_now(la - 1, lav);
+    else
+        __syncthreads();
+    check();
+    if (!stop) publish(candidate(phase));
+
+    while (!stop) {
+        // ---------------- gather everyone's candidate -------------------------------------------
+        const int par = epoch & 1;
+        KI c = {INFINITY, INT_MAX};
+        if (tid < NB) {
+            unsigned long long f = 0;
+            unsigned spins = 0;
+            unsigned long long spin_t0 = 0;
+            double2 rec;
+            for (;;) {
+                rec = ld16_sc1_one(d.rc_flag[par] + 2 * tid);
+                f = (unsigned long long)__double_as_longlong(rec.y);
+                if ((unsigned)(f >> 32) == epoch) break;
+                if (spin_expired(spins, spin_t0, d.rc_err)) {
+                    sh_fail = 1;
+                    __hip_atomic_store(d.rc_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            c.i = (int)(unsigned)f;
+            c.k = rec.x;
+        }
+        c = block_argmin<T>(c, sk, si, slot); // (its barrier is the one the polling waves join)
+        slot ^= 1;
+        if (sh_fail) return; // uniform: written before the barrier above
+        if (c.i == INT_MAX) {
+            if (phase == 1) { // :120 phase 1 is over: same tableau, now the min-ratio exchange
+                phase = 2;
+                iter = 0.0;
+                check();
+                if (!stop) {
+                    if (la > 0)
+                        column_now(la - 1, lav);
+                    else
+                        __syncthreads();
+                    publish(candidate(2));
+                }
+            } else {
+                term = YALPS_UNBOUNDED; // :96
+                term_result = (double)la;
+                stop = true;
+            }
+            continue;
+        }
+        const int row_in = c.i, row = (unsigned)row_in < (unsigned)h ? row_in : 0, owner = row % NB;
+        if (row != row_in && tid == 0) __hip_atomic_store(d.rc_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (never expected)
+        const int lslot = owner == b ? row / NB : -1; // my slot of the pivot row, if I own it
+        // ---------------- the winner's row as published: the tableau's row after every earlier pivot ----------------
+        const double *src = d.rc_rows[par] + (size_t)owner * pitch;
+        const double rhs_row = ld_sc1(d.rc_key[par] + owner);
+        double2 pv[J];
+        ld16_sc1<J>(pv, src, cofs);
+        int col = la;
+        if (phase == 1) { // :123-134
+            KI e = {INFINITY, INT_MAX};
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                const int c0 = 2 * (tid + j * T);
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const double coefficient = elem(pv[j], k);
+                    if (c0 + k < n && coefficient < -precision) {
+                        const double ratio = -elem(o[j], k) / coefficient;
+                        if (ratio > -INFINITY && ki_better(-ratio, c0 + k + 1, e.k, e.i)) {
+                            e.k = -ratio;
+                            e.i = c0 + k + 1;
+                        }
+                    }
+                }
+            }
+            e = block_argmin<T>(e, sk, si, slot);
+            slot ^= 1;
+            if (e.i == INT_MAX) { // :135
+                term = YALPS_INFEASIBLE;
+                stop = true;
+                continue;
+            }
+            col = e.i;
+        }
+        // ---------------- pivot (src/simplex.ts:5-39): it becomes pending pivot number npend ---------------------------
+        const int colx = col - 1, ucol = colx >> 1, ecol = colx & 1, col_tid = ucol % T, col_j = ucol / T;
+        double *prowN = npend ? prow1 : prow0, *colvN = npend ? colv1 : colv0;
+        // my rows' pivot-column entries as they are now (gather + the older pending pivot), the objective row's entry and
+        // the quotient (from the lane that holds that column)
+        if (tid == col_tid) {
+#pragma unroll
+            for (int j = 0; j < J; j++)
+                if (j == col_j) {
+                    sh_c0 = elem(o[j], ecol);
+                    sh_q = elem(pv[j], ecol);
+                }
+        }
+        column_now(colx, colvN); // (its barrier also publishes sh_q / sh_c0)
+        const double q = sh_q, coef0 = sh_c0, inv_q = 1.0 / q;
+        // normalised pivot row -> LDS (:14-25); pv keeps the normalised values (0.0 where flushed) for the objective replica
+        unsigned nzmask = 0;
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            const int c0 = 2 * (tid + j * T);
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const double v = elem(pv[j], k);
+                const bool nz = fabs(v) > 1e-16;
+                pv[j] = with_elem(pv[j], k, nz ? v / q : 0.0);
+                if (nz) nzmask |= 1u << (2 * j + k);
+            }
+            if (c0 < pitch)
+                *reinterpret_cast<double2 *>(prowN + c0) = make_double2((nzmask & (1u << (2 * j))) ? pv[j].x : flushed,
+                                                                        (nzmask & (1u << (2 * j + 1))) ? pv[j].y : flushed);
+        }
+        const bool nz_rhs = fabs(rhs_row) > 1e-16;
+        const double pn_rhs = nz_rhs ? rhs_row / q : 0.0;
+        for (int i = tid; i < my_rows; i += T) { // RHS entries of my rows (:33 at column 0)
+            const double coef = colvN[i];
+            if (i == lslot)
+                rhsv[i] = pn_rhs;
+            else if (fabs(coef) > 1e-16 && nz_rhs) {
+                const double prod = coef * pn_rhs;
+                rhsv[i] = rhsv[i] - prod;
+            }
+        }
+        if (fabs(coef0) > 1e-16) { // my replica of the objective row
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                const double px = coef0 * pv[j].x, py = coef0 * pv[j].y;
+                const double nx = o[j].x - px, ny = o[j].y - py;
+                o[j].x = (nzmask & (1u << (2 * j))) ? nx : o[j].x;
+                o[j].y = (nzmask & (1u << (2 * j + 1))) ? ny : o[j].y;
+                if (tid == col_tid && j == col_j) o[j] = with_elem(o[j], ecol, -coef0 / q); // :36
+            }
+        }
+        if (npend == 0) {
+            lslot0 = lslot;
+            colx0 = colx;
+            q0 = q;
+            invq0 = inv_q;
+        } else {
+            lslot1 = lslot;
+            colx1 = colx;
+            q1 = q;
+            invq1 = inv_q;
+        }
+        npend += 1;
+        iter += 1.0;
+        pivots += 1;
+        done += 1;
+        price(); // la of the next pivot (its barrier also publishes prow / rhsv to the workgroup)
+        check();
+        if (!stop) {
+            if (phase == 2) column_now(la - 1, lav); // my rows' entries of column la after every pivot so far
+            publish(candidate(phase));               // (la > 0 here: check() stops phase 2 without an entering column)
+        }
+        if (b == 0 && tid == 0) { // basis bookkeeping, :7-12 (off the critical path)
+            const int leaving = d.var[w + row], entering = d.var[col];
+            d.var[w + row] = entering;
+            d.var[col] = leaving;
+            d.pos[leaving] = col;
+            d.pos[entering] = w + row;
+        }
+        // ---------------- the rows: only every second pivot (or on the way out) ------------------------------------------
+        if (npend == 2 || stop)
+            flush_pending();
+        else
+            __syncthreads(); // (colv / rhsv / lav of this pivot are complete before the next round's lanes read them)
+    }
+    flush_pending(); // (a pivot decided before a break out of the loop: unbounded / infeasible leave with one pending)
+
+    // ---------------- leave: RHS column, state (the rows are where they were) --------------------
+    for (int i = tid; i < my_rows; i += T) rhs[b + NB * i] = rhsv[i];
+    if (b == 0 && tid == 0) {
+        if (term == YALPS_OPTIMAL) term_result = round_to_precision(rhsv[0], precision);
+        Sout->status = term;
+        Sout->phase = phase;
+        Sout->bootstrap = 1; // the launch-per-pivot kernels would have to re-scan
+        Sout->la = 0;
+        Sout->pbuf = 0;
+        Sout->mbuf = mbuf;
+        Sout->pause = 0;
+        Sout->dec_valid = 0;
+        Sout->dec_row = 0;
+        Sout->dec_col = 0;
+        Sout->swap_valid = 0;
+        Sout->swap_row = 0;
+        Sout->swap_col = 0;
+        Sout->pad_ = 0;
+        Sout->hist_len = hist_len;
+        Sout->iter = iter;
+        Sout->result = term_result;
+        Sout->pivots = pivots;
+    }
+}

@@ -140,6 +140,7 @@ const std::vector<RVariant> kStreamCheck = variants_of({yalps_stream_check_table
 // 4098 .. 8193-column tableaux beyond the Infinity Cache)
 const std::vector<RVariant> kSweep = variants_of({yalps_sweep_table()});
 const std::vector<RVariant> kSweepCheck = variants_of({yalps_sweep_check_table()});
+const std::vector<RVariant> kStream2 = variants_of({yalps_stream2_table()}); // (R = non-temporal row traffic)
 constexpr size_t SWEEP_BEYOND_CACHE = 200u << 20; // tableau bytes from which row traffic goes non-temporal (Infinity Cache: 256 MiB)
 constexpr int RESIDENT_CHUNK = 4096; // pivots per launch of the resident kernel (bounds its run time)
 
@@ -269,6 +270,10 @@ struct yalps_tableau {
     RVariant svar{0, 0, 0, nullptr}; // stream_kernel variant (persistent, in place)
     RVariant svar_check{0, 0, 0, nullptr}; // the same with hasCycle (options.checkCycles)
     bool sweep = false;                    // svar / svar_check are sweep_kernel variants
+    RVariant svar2{0, 0, 0, nullptr};      // stream2_kernel variant: two pivots per sweep (taken without checkCycles; YALPS_HIP_DELAY=0: never)
+    size_t sshmem2 = 0;
+    bool sattr2 = false;
+    bool last_delayed = true; // what the last in-place solve ran (before the first one: what it would run)
     bool sattr_check = false;
     size_t sshmem = 0;
     bool sattr = false;
@@ -661,6 +666,19 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
             if (v.T == T && v.J == J) t->svar_check = v;
         t->sshmem = sizeof(double) * ((size_t)d.pitch + 3 * (size_t)rows_per_block) + sizeof(int32_t) * (size_t)rows_per_block;
         if (t->sshmem > 150 * 1024) t->svar.fn = t->svar_check.fn = nullptr;
+        // two pivots per sweep where stream_kernel's lanes x units span the row and two pivot rows fit in LDS
+        if (t->svar.fn && env_int("YALPS_HIP_DELAY", 1)) {
+            const size_t tab_bytes2 = sizeof(double) * (size_t)d.pitch * hcap;
+            int want_nt2 = tab_bytes2 > SWEEP_BEYOND_CACHE ? 1 : 0;
+            if (const char *e = std::getenv("YALPS_HIP_DELAY_NT")) want_nt2 = std::atoi(e) != 0;
+            const size_t lds2 = sizeof(double) * (2 * (size_t)d.pitch + 4 * (size_t)rows_per_block) + sizeof(int32_t) * (size_t)rows_per_block;
+            if (lds2 <= 150 * 1024) {
+                for (int nt = want_nt2; nt >= 0 && !t->svar2.fn; nt--) // (the plain form where no non-temporal one is built)
+                    for (const RVariant &v : kStream2)
+                        if (v.T == T && v.J == J && v.R == nt) t->svar2 = v;
+                t->sshmem2 = lds2;
+            }
+        }
         // what streams from HBM anyway goes to sweep_kernel: rows of 8194 .. 16385 columns (no stream_kernel spans them), and
         // 4098 .. 8193-column tableaux too big for the Infinity Cache (measured at 8193 x 8193: stream_kernel 5.1 TB/s)
         const size_t tab_bytes = sizeof(double) * (size_t)d.pitch * hcap;
@@ -783,7 +801,10 @@ int32_t yalps_tableau_info(const yalps_tableau *t, char *buf, int32_t len) {
     if (t->rvar.fn)
         std::snprintf(res, sizeof res, "resident%s_kernel<%d,%d,%d%s> chunk=%d lds_rows=%d", t->rgen == 2 && !t->rvar_tag.fn ? "2" : "", t->rvar.T, t->rvar.J, t->rvar.R,
                       t->d.extra ? ",lds" : t->rvar_tag.fn ? ",tag" : "", RESIDENT_CHUNK, t->d.extra);
-    if (t->svar.fn) std::snprintf(inp, sizeof inp, "%s_kernel<%d,%d%s>", t->sweep ? "sweep" : "stream", t->svar.T, t->svar.J, t->sweep && t->d.sw_nt ? ",nt" : "");
+    if (t->svar2.fn && t->last_delayed)
+        std::snprintf(inp, sizeof inp, "stream2_kernel<%d,%d%s>", t->svar2.T, t->svar2.J, t->svar2.R ? ",nt" : "");
+    else if (t->svar.fn)
+        std::snprintf(inp, sizeof inp, "%s_kernel<%d,%d%s>", t->sweep ? "sweep" : "stream", t->svar.T, t->svar.J, t->sweep && t->d.sw_nt ? ",nt" : "");
     char str[64];
     if (t->wfn)
         std::snprintf(str, sizeof str, "wide_kernel<%d,%d>", t->var.T, t->var.J);
@@ -1201,9 +1222,11 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
         const bool use_stream = persistent_ok && !use_resident && inplace_on && c->inplace_skip == 0 && (checkCycles ? t->svar_check.fn : t->svar.fn);
         if (!use_resident && !use_stream) break;
         const bool in_place = use_stream;
-        const RVariant &pv = in_place ? (checkCycles ? t->svar_check : t->svar) : t->rvar_tag.fn ? t->rvar_tag : t->rvar;
-        bool &sattr = checkCycles ? t->sattr_check : t->sattr;
-        const size_t shmem = in_place ? t->sshmem : t->rx_shmem ? t->rx_shmem : sizeof(int32_t) * 2 * (size_t)t->perm_len;
+        const bool delayed = in_place && !checkCycles && t->svar2.fn; // stream2_kernel: two pivots per sweep
+        if (in_place) t->last_delayed = delayed;
+        const RVariant &pv = delayed ? t->svar2 : in_place ? (checkCycles ? t->svar_check : t->svar) : t->rvar_tag.fn ? t->rvar_tag : t->rvar;
+        bool &sattr = delayed ? t->sattr2 : checkCycles ? t->sattr_check : t->sattr;
+        const size_t shmem = delayed ? t->sshmem2 : in_place ? t->sshmem : t->rx_shmem ? t->rx_shmem : sizeof(int32_t) * 2 * (size_t)t->perm_len;
         if (in_place ? !sattr : shmem != t->rshmem) {
             if (shmem > 48 * 1024)
                 if (int rc2 = allow_big_lds(c->device, reinterpret_cast<const void *>(pv.fn))) return rc2;
@@ -1222,7 +1245,9 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
                     std::fprintf(stderr, "yalps_hip: %s<%d,%d,%d>: %d workgroups do not fit on %d CUs x %d; using the next path\n",
                                  in_place ? "stream_kernel" : "resident_kernel", pv.T, pv.J, pv.R, t->nb, c->num_cus, per_cu);
                 t->occupancy_warned = true;
-                if (in_place)
+                if (delayed)
+                    t->svar2.fn = nullptr;
+                else if (in_place)
                     t->svar.fn = t->svar_check.fn = nullptr;
                 else
                     t->rvar.fn = t->rvar_tag.fn = nullptr;
