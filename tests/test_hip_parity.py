@@ -608,7 +608,7 @@ def test_two_tableaux_share_a_kernel_with_different_lds_needs(nat, ctx):
             t, m, w, h, pos = tabs[k]
             t.upload(m, h, pos, pos.copy())
             st, res, piv, _ = t.solve(max_pivots=20)
-            assert t.info()["last_path"] == "inplace" and t.info()["inplace"] == "stream2_kernel<1024,4>", t.info()
+            assert t.info()["last_path"] == "inplace" and t.info()["inplace"] == "stream2_kernel<512,8>", t.info()
             runs.append((k, st, res, piv, t.download()))
     finally:
         for t, *_ in tabs:
@@ -860,9 +860,9 @@ SWEEP = [  # M, N, pivots, env, expected kernel, checkCycles
     (2500, 5000, 60, {"YALPS_HIP_SWEEP": "2", "YALPS_HIP_SWEEP_NT": "1", "YALPS_HIP_DELAY": "0"}, "sweep_kernel<512,8,nt>", False),
     (900, 7000, 60, {"YALPS_HIP_SWEEP": "2"}, "sweep_kernel<512,8>", True),
     # stream2_kernel (two pivots per sweep) with the same awkward data; its non-temporal forms; odd budgets
-    (1400, 8000, 81, {"YALPS_HIP_DELAY_NT": "1"}, "stream2_kernel<1024,4,nt>", False),
+    (1400, 8000, 81, {"YALPS_HIP_DELAY_NT": "1"}, "stream2_kernel<512,8,nt>", False),
     (4300, 4000, 61, {"YALPS_HIP_DELAY_NT": "1"}, "stream2_kernel<1024,2,nt>", False),
-    (900, 7000, 60, {}, "stream2_kernel<1024,4>", False),
+    (900, 7000, 60, {}, "stream2_kernel<512,8>", False),
 ]
 
 

@@ -84,6 +84,8 @@ struct Desc {
     // whether the row traffic is non-temporal (tableau beyond the Infinity Cache)
     unsigned long long *sw_sync, *sw_recs;
     int32_t sw_nt;
+    // stream2_kernel: pivots whose eliminations are delayed and carried out together (as many pivot rows as LDS holds, <= 8)
+    int32_t delay_depth;
     // row shards swept IN PLACE (wide_kernel<.., true, ..>): the objective row is the one row every workgroup reads while
     // its owner rewrites it, so it alone stays ping-ponged, as two replicas [pitch] beside the tableau
     double *obj[2];

@@ -20,8 +20,10 @@ namespace {
 } // namespace
 PersistentTable yalps_stream2_table() {
     static const PersistentEntry kStream2[] = {
-        S2VARIANT(256, 1, 0), S2VARIANT(256, 2, 0), S2VARIANT(1024, 1, 0), S2VARIANT(1024, 2, 0), S2VARIANT(1024, 4, 0),
-        S2VARIANT(1024, 2, 1), S2VARIANT(1024, 4, 1),
+        // (one variant per row span T * J; 4096 units: 512 lanes x 8 -- three 8-unit row buffers need the 256 registers of a
+        // 512-lane workgroup, <1024,4> has 128 and room for one)
+        S2VARIANT(256, 1, 0), S2VARIANT(256, 2, 0), S2VARIANT(1024, 1, 0), S2VARIANT(1024, 2, 0), S2VARIANT(512, 8, 0),
+        S2VARIANT(1024, 2, 1), S2VARIANT(512, 8, 1),
     };
     return {kStream2, (int)(sizeof kStream2 / sizeof kStream2[0])};
 }

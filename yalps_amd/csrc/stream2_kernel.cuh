@@ -1,4 +1,4 @@
-// stream2_kernel.cuh -- persistent in-place pivot loop with the row updates DELAYED by one pivot (two pivots per sweep)
+// stream2_kernel.cuh -- persistent in-place pivot loop with the row updates DELAYED: up to d.delay_depth pivots per sweep
 // Part of libyalps_hip.so; included by persistent_stream2.hip inside its unnamed namespace (gfx950 only).
 #pragma once
 
@@ -15,11 +15,13 @@
 //     flops per row;
 //   * my candidate row for the next exchange is loaded, run through the pending pivots in registers and published -- it
 //     alone, not stored.
-// When TWO pivots are pending (or the loop stops) every touched row is streamed ONCE and gets both eliminations in
-// registers, each with its own separately rounded multiply and subtract in the reference's order: bit for bit what two
-// sweeps leave, at half the traffic.  The exchange is unchanged: one per pivot.
-// Per pivot an element costs 8 instead of 16 bytes of HBM traffic: where stream_kernel / sweep_kernel sit on the memory
-// roofline (4097 x 4097: 38 us per pivot out of the Infinity Cache, 8193 x 8193: 183 us out of HBM) this one moves half.
+// When d.delay_depth pivots are pending (2 .. 8: as many normalised pivot rows as fit in LDS; or the loop stops) every
+// touched row is streamed ONCE and gets all pending eliminations in registers, oldest first, each with its own separately
+// rounded multiply and subtract in the reference's order: bit for bit what that many sweeps leave, at 1/depth of the
+// traffic.  The exchange is unchanged: one per pivot.
+// Per pivot an element costs 16 / depth bytes of HBM traffic instead of 16: where stream_kernel / sweep_kernel sit on the
+// memory roofline (4097 x 4097: 38 us per pivot out of the Infinity Cache, 8193 x 8193: 183 us out of HBM) this one moves
+// a half to an eighth; what remains per pivot is the exchange (~10 us).
 // No checkCycles (those solves keep stream_kernel).  NT: non-temporal row traffic (tableaux beyond the Infinity Cache).
 // ------------------------------------------------------------------------------------------
 template <int T, int J, bool NT>
@@ -28,7 +30,10 @@ __global__ __launch_bounds__(T) void stream2_kernel(Desc d, int parity, int chun
     __shared__ int si[2][16];
     __shared__ double sh_q, sh_c0; // quotient; objective-row entry of the pivot column
     __shared__ int sh_fail, sh_nt;
-    extern __shared__ double sm_dyn[]; // prow[2][pitch], colv[2][rpw], lav[rpw], rhsv[rpw], tlist[rpw] (int)
+    constexpr int MAXD = 4;
+    __shared__ int sh_pl[MAXD], sh_pc[MAXD]; // the pending pivots, oldest first: my slot of the pivot row (-1: not mine), pivot column (mat index)
+    __shared__ int sh_fast[MAXD][T / 64];       // per wave: nothing of its slice of that pivot row was flushed (:31 select-free path)
+    extern __shared__ double sm_dyn[]; // prow[depth][pitch], colv[depth][rpw], nqv[depth][rpw], lav[rpw], rhsv[rpw], tlist[rpw] (int)
 
     const int tid = threadIdx.x, NB = d.nb, b = blockIdx.x;
     const YState *Sin = d.st + parity;
@@ -50,7 +55,9 @@ __global__ __launch_bounds__(T) void stream2_kernel(Desc d, int parity, int chun
     int slot = 0;
     const int rpw = (d.hcap + NB - 1) / NB;
     const int my_rows = b < h ? (h - 1 - b) / NB + 1 : 0;
-    double *prow0 = sm_dyn, *prow1 = prow0 + pitch, *colv0 = prow1 + pitch, *colv1 = colv0 + rpw, *lav = colv1 + rpw, *rhsv = lav + rpw;
+    const int depth = d.delay_depth < 1 ? 1 : d.delay_depth > MAXD ? MAXD : d.delay_depth;
+    double *prow0 = sm_dyn, *colv0 = prow0 + (size_t)depth * pitch, *nqv0 = colv0 + (size_t)depth * rpw, *lav = nqv0 + (size_t)depth * rpw,
+           *rhsv = lav + rpw; // (nqv: what replaces a row's pivot-column entry, :25 / :36 -- one division per row and pivot, by one lane)
     int *tlist = reinterpret_cast<int *>(rhsv + rpw);
     const double flushed = __longlong_as_double((long long)FLUSHED);
 
@@ -60,6 +67,13 @@ __global__ __launch_bounds__(T) void stream2_kernel(Desc d, int parity, int chun
         const int c0 = 2 * (tid + j * T);
         cofs[j] = c0 < pitch ? c0 : 0;
     }
+    unsigned padmask = 0; // columns of mine that do not exist (c0 + k >= n): 0.0 in a pivot row, must not count as "flushed"
+#pragma unroll
+    for (int j = 0; j < J; j++)
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+            if (2 * (tid + j * T) + k >= n) padmask |= 1u << (2 * j + k);
+    constexpr unsigned FULL = (1u << (2 * J)) - 1u;
     // ---- my replica of the objective row (registers), my rows' RHS (LDS) ----
     double2 o[J];
 #pragma unroll
@@ -68,19 +82,17 @@ __global__ __launch_bounds__(T) void stream2_kernel(Desc d, int parity, int chun
     if (tid == 0) sh_fail = 0;
     __syncthreads();
 
-    // ---- the pending pivots (at most two; [0] is the older): scalars in registers, rows and columns in LDS ----
+    // ---- the pending pivots (npend of them, [0] the oldest): scalars, pivot rows and my rows' pivot-column entries in LDS ----
     int npend = 0;
-    int lslot0 = -1, lslot1 = -1, colx0 = 0, colx1 = 0;
-    double q0 = 1.0, q1 = 1.0, invq0 = 1.0, invq1 = 1.0;
     // entry (my row slot i, mat column c) after ONE pending pivot, given the entry before it (:14-25, :31-36 for one element)
-    auto after1 = [&](const double *prowp, const double *colvp, int lslotp, int colxp, double qp, double invqp, int i, double v, int c)
+    auto after1 = [&](const double *prowp, const double *colvp, const double *nqvp, int lslotp, int colxp, int i, double v, int c)
                       __attribute__((always_inline)) {
         const double p = prowp[c];
         const bool pnz = (unsigned long long)__double_as_longlong(p) != FLUSHED;
         const double coef = colvp[i];
-        if (i == lslotp) return c == colxp ? invqp : (pnz ? p : 0.0);
+        if (i == lslotp) return c == colxp ? nqvp[i] : (pnz ? p : 0.0);
         if (fabs(coef) > 1e-16) {
-            if (c == colxp) return -coef / qp;
+            if (c == colxp) return nqvp[i];
             if (pnz) {
                 const double prod = coef * p;
                 return v - prod;
@@ -92,20 +104,34 @@ __global__ __launch_bounds__(T) void stream2_kernel(Desc d, int parity, int chun
     auto column_now = [&](int c, double *out) __attribute__((always_inline)) {
         for (int i = tid; i < my_rows; i += T) {
             double v = ld_sc1(mat + (size_t)(b + NB * i) * pitch + c);
-            if (npend >= 1) v = after1(prow0, colv0, lslot0, colx0, q0, invq0, i, v, c);
-            if (npend >= 2) v = after1(prow1, colv1, lslot1, colx1, q1, invq1, i, v, c);
+            for (int p = 0; p < npend; p++) v = after1(prow0 + (size_t)p * pitch, colv0 + p * rpw, nqv0 + p * rpw, sh_pl[p], sh_pc[p], i, v, c);
             out[i] = v;
         }
         __syncthreads();
     };
     // one pending pivot applied to a whole row slice held in registers (the same arithmetic as stream_kernel's finish_row)
-    auto apply_row = [&](const double *prowp, const double *colvp, int lslotp, int colxp, double qp, double invqp, int i, double2 (&x)[J])
+    auto apply_row = [&](const double *prowp, bool is_piv, double coef, double patch, int colxp, bool fastp, double2 (&x)[J])
                          __attribute__((always_inline)) {
-        const double coef = colvp[i];
-        const bool is_piv = i == lslotp;
         const bool act = !is_piv && fabs(coef) > 1e-16; // :31
         if (!is_piv && !act) return;
-        const double patch = is_piv ? invqp : -coef / qp; // :25 / :36
+        if (fastp && !is_piv) { // nothing of this wave's slice was flushed: two fp64 instructions per element, no select
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                const int c0 = 2 * (tid + j * T);
+                if (c0 >= pitch) continue;
+                const double2 pn = *reinterpret_cast<const double2 *>(prowp + c0);
+                const double px = coef * pn.x, py = coef * pn.y;
+                x[j].x = x[j].x - px;
+                x[j].y = x[j].y - py;
+                if (c0 == (colxp & ~1)) {
+                    if (colxp & 1)
+                        x[j].y = patch;
+                    else
+                        x[j].x = patch;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < J; j++) {
             const int c0 = 2 * (tid + j * T);
@@ -130,9 +156,25 @@ __global__ __launch_bounds__(T) void stream2_kernel(Desc d, int parity, int chun
             }
         }
     };
+    // (the pending pivots' wave-uniform scalars are read once per use of apply_pending's caller into registers -- p is a
+    // compile-time index there --; per row and pivot two LDS words remain: the row's coefficient and its patch value.  With
+    // every scalar re-read and -coef/quotient re-divided per row and pivot, by every wave, a row cost 0.85 us per pending
+    // pivot: more than its memory traffic)
+    int pcx[MAXD], pls[MAXD];
+    bool pfast[MAXD];
+    auto pending_scalars = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < MAXD; p++) {
+            pcx[p] = p < npend ? sh_pc[p] : 0;
+            pls[p] = p < npend ? sh_pl[p] : -1;
+            pfast[p] = p < npend ? sh_fast[p][tid >> 6] != 0 : false;
+        }
+    };
     auto apply_pending = [&](int i, double2 (&x)[J]) __attribute__((always_inline)) {
-        if (npend >= 1) apply_row(prow0, colv0, lslot0, colx0, q0, invq0, i, x);
-        if (npend >= 2) apply_row(prow1, colv1, lslot1, colx1, q1, invq1, i, x);
+#pragma unroll
+        for (int p = 0; p < MAXD; p++)
+            if (p < npend) // (uniform)
+                apply_row(prow0 + (size_t)p * pitch, i == pls[p], colv0[p * rpw + i], nqv0[p * rpw + i], pcx[p], pfast[p], x);
     };
     auto load_row = [&](int i, double2 (&x)[J]) __attribute__((always_inline)) {
         const double *m = mat + (size_t)(b + NB * i) * pitch;
@@ -159,10 +201,8 @@ __global__ __launch_bounds__(T) void stream2_kernel(Desc d, int parity, int chun
             for (int base = 0; base < my_rows; base += 64) {
                 const int i = base + tid;
                 bool t = false;
-                if (i < my_rows) {
-                    t = i == lslot0 || fabs(colv0[i]) > 1e-16;
-                    if (npend >= 2) t = t || i == lslot1 || fabs(colv1[i]) > 1e-16;
-                }
+                if (i < my_rows)
+                    for (int p = 0; p < npend; p++) t = t || i == sh_pl[p] || fabs(colv0[p * rpw + i]) > 1e-16;
                 const unsigned long long m = __ballot(t);
                 if (t) tlist[cnt + __popcll(m & ((1ull << tid) - 1ull))] = i;
                 cnt += __popcll(m);
@@ -171,29 +211,26 @@ __global__ __launch_bounds__(T) void stream2_kernel(Desc d, int parity, int chun
         }
         __syncthreads();
         const int nt = sh_nt;
-        if constexpr (J <= 2) { // two row buffers taking turns
-            if (nt > 0) {
-                double2 xa[J], xb[J];
-                load_row(tlist[0], xa);
-                for (int k = 0; k < nt; k += 2) {
-                    const int i0 = tlist[k], i1 = tlist[k + 1 < nt ? k + 1 : k], i2 = tlist[k + 2 < nt ? k + 2 : k];
-                    if (k + 1 < nt) load_row(i1, xb);
-                    apply_pending(i0, xa);
-                    store_row(i0, xa);
-                    if (k + 2 < nt) load_row(i2, xa);
-                    if (k + 1 < nt) {
-                        apply_pending(i1, xb);
-                        store_row(i1, xb);
+        pending_scalars();
+        // NBUF row buffers taking turns: NBUF - 1 rows' loads are in flight while one row gets its eliminations and is stored
+        // (a wave's rows are a dependent load -> compute -> store chain each: with one row ahead the sweep ran at the
+        // latency of a row, 2 us, not at the bandwidth of the memory: 4097 x 4097 spent 1.0 us per row and pivot)
+        constexpr int NBUF = J <= 2 ? 4 : 3;
+        {
+            double2 xb[NBUF][J];
+#pragma unroll
+            for (int u = 0; u < NBUF - 1; u++)
+                if (u < nt) load_row(tlist[u], xb[u]);
+            for (int k = 0; k < nt; k += NBUF) {
+#pragma unroll
+                for (int u = 0; u < NBUF; u++) {
+                    if (k + u + NBUF - 1 < nt) load_row(tlist[k + u + NBUF - 1], xb[(u + NBUF - 1) % NBUF]);
+                    if (k + u < nt) {
+                        const int i0 = tlist[k + u];
+                        apply_pending(i0, xb[u]);
+                        store_row(i0, xb[u]);
                     }
                 }
-            }
-        } else {
-            for (int k = 0; k < nt; k++) {
-                const int i0 = tlist[k];
-                double2 xa[J];
-                load_row(i0, xa);
-                apply_pending(i0, xa);
-                store_row(i0, xa);
             }
         }
         npend = 0;
@@ -260,6 +297,7 @@ __global__ __launch_bounds__(T) void stream2_kernel(Desc d, int parity, int chun
             const double *m = mat + (size_t)(b + NB * cg) * pitch;
 #pragma unroll
             for (int j = 0; j < J; j++) x[j] = *reinterpret_cast<const double2 *>(m + cofs[j]);
+            pending_scalars();
             apply_pending(cg, x);
             double *dst = d.rc_rows[par] + (size_t)b * pitch;
 #pragma unroll
@@ -381,8 +419,8 @@ __global__ __launch_bounds__(T) void stream2_kernel(Desc d, int parity, int chun
         }
         // ---------------- pivot (src/simplex.ts:5-39): it becomes pending pivot number npend ---------------------------
         const int colx = col - 1, ucol = colx >> 1, ecol = colx & 1, col_tid = ucol % T, col_j = ucol / T;
-        double *prowN = npend ? prow1 : prow0, *colvN = npend ? colv1 : colv0;
-        // my rows' pivot-column entries as they are now (gather + the older pending pivot), the objective row's entry and
+        double *prowN = prow0 + (size_t)npend * pitch, *colvN = colv0 + npend * rpw, *nqvN = nqv0 + npend * rpw;
+        // my rows' pivot-column entries as they are now (gather + the older pending pivots), the objective row's entry and
         // the quotient (from the lane that holds that column)
         if (tid == col_tid) {
 #pragma unroll
@@ -392,7 +430,15 @@ __global__ __launch_bounds__(T) void stream2_kernel(Desc d, int parity, int chun
                     sh_q = elem(pv[j], ecol);
                 }
         }
-        column_now(colx, colvN); // (its barrier also publishes sh_q / sh_c0)
+        if (phase == 2) {
+            // (phase 2 enters column la, whose entries of my rows "as of now" are what the look-ahead computed for the ratio
+            // test: the same routine on the same pending pivots, or -- after a flush -- the same arithmetic carried out on
+            // the rows; no gather, one trip through the fabric less on every pivot's chain)
+            for (int i = tid; i < my_rows; i += T) colvN[i] = lav[i];
+            __syncthreads(); // (also publishes sh_q / sh_c0)
+        } else {
+            column_now(colx, colvN); // (its barrier also publishes sh_q / sh_c0)
+        }
         const double q = sh_q, coef0 = sh_c0, inv_q = 1.0 / q;
         // normalised pivot row -> LDS (:14-25); pv keeps the normalised values (0.0 where flushed) for the objective replica
         unsigned nzmask = 0;
@@ -410,6 +456,10 @@ __global__ __launch_bounds__(T) void stream2_kernel(Desc d, int parity, int chun
                 *reinterpret_cast<double2 *>(prowN + c0) = make_double2((nzmask & (1u << (2 * j))) ? pv[j].x : flushed,
                                                                         (nzmask & (1u << (2 * j + 1))) ? pv[j].y : flushed);
         }
+        {
+            const bool fast = __builtin_amdgcn_ballot_w64(((nzmask | padmask) & FULL) != FULL) == 0; // (per wave)
+            if ((tid & 63) == 0) sh_fast[npend][tid >> 6] = fast ? 1 : 0;
+        }
         const bool nz_rhs = fabs(rhs_row) > 1e-16;
         const double pn_rhs = nz_rhs ? rhs_row / q : 0.0;
         for (int i = tid; i < my_rows; i += T) { // RHS entries of my rows (:33 at column 0)
@@ -420,6 +470,7 @@ __global__ __launch_bounds__(T) void stream2_kernel(Desc d, int parity, int chun
                 const double prod = coef * pn_rhs;
                 rhsv[i] = rhsv[i] - prod;
             }
+            nqvN[i] = i == lslot ? inv_q : -coef / q; // what replaces the pivot column (:25, :36)
         }
         if (fabs(coef0) > 1e-16) { // my replica of the objective row
 #pragma unroll
@@ -431,16 +482,9 @@ __global__ __launch_bounds__(T) void stream2_kernel(Desc d, int parity, int chun
                 if (tid == col_tid && j == col_j) o[j] = with_elem(o[j], ecol, -coef0 / q); // :36
             }
         }
-        if (npend == 0) {
-            lslot0 = lslot;
-            colx0 = colx;
-            q0 = q;
-            invq0 = inv_q;
-        } else {
-            lslot1 = lslot;
-            colx1 = colx;
-            q1 = q;
-            invq1 = inv_q;
+        if (tid == 0) { // (published to the workgroup by price()'s barrier, like prow / rhsv)
+            sh_pl[npend] = lslot;
+            sh_pc[npend] = colx;
         }
         npend += 1;
         iter += 1.0;
@@ -459,8 +503,8 @@ __global__ __launch_bounds__(T) void stream2_kernel(Desc d, int parity, int chun
             d.pos[leaving] = col;
             d.pos[entering] = w + row;
         }
-        // ---------------- the rows: only every second pivot (or on the way out) ------------------------------------------
-        if (npend == 2 || stop)
+        // ---------------- the rows: only every depth-th pivot (or on the way out) ----------------------------------------
+        if (npend == depth || stop)
             flush_pending();
         else
             __syncthreads(); // (colv / rhsv / lav of this pivot are complete before the next round's lanes read them)

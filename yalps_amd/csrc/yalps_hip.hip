@@ -671,12 +671,18 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
             const size_t tab_bytes2 = sizeof(double) * (size_t)d.pitch * hcap;
             int want_nt2 = tab_bytes2 > SWEEP_BEYOND_CACHE ? 1 : 0;
             if (const char *e = std::getenv("YALPS_HIP_DELAY_NT")) want_nt2 = std::atoi(e) != 0;
-            const size_t lds2 = sizeof(double) * (2 * (size_t)d.pitch + 4 * (size_t)rows_per_block) + sizeof(int32_t) * (size_t)rows_per_block;
-            if (lds2 <= 150 * 1024) {
+            // as many pending pivots as LDS holds normalised pivot rows (+ two scalars per row of mine) for, at most 4:
+            // the rows then cost 16 / depth bytes of traffic per element and pivot (YALPS_HIP_DELAY_DEPTH caps it)
+            const size_t per_pivot = sizeof(double) * ((size_t)d.pitch + 2 * (size_t)rows_per_block);
+            const size_t fixed = sizeof(double) * 2 * (size_t)rows_per_block + sizeof(int32_t) * (size_t)rows_per_block;
+            int depth = (int)std::min<size_t>(4, (150 * 1024 - fixed) / per_pivot);
+            depth = std::min(depth, std::max(1, env_int("YALPS_HIP_DELAY_DEPTH", 4))); // (measured: 4 as good as 8, 5001 x 5001 10 % better than 2)
+            if (depth >= 2) {
                 for (int nt = want_nt2; nt >= 0 && !t->svar2.fn; nt--) // (the plain form where no non-temporal one is built)
                     for (const RVariant &v : kStream2)
-                        if (v.T == T && v.J == J && v.R == nt) t->svar2 = v;
-                t->sshmem2 = lds2;
+                        if (v.T * v.J == T * J && v.R == nt) t->svar2 = v; // (same row span; its own lane count)
+                t->sshmem2 = fixed + (size_t)depth * per_pivot;
+                d.delay_depth = depth;
             }
         }
         // what streams from HBM anyway goes to sweep_kernel: rows of 8194 .. 16385 columns (no stream_kernel spans them), and
@@ -802,7 +808,7 @@ int32_t yalps_tableau_info(const yalps_tableau *t, char *buf, int32_t len) {
         std::snprintf(res, sizeof res, "resident%s_kernel<%d,%d,%d%s> chunk=%d lds_rows=%d", t->rgen == 2 && !t->rvar_tag.fn ? "2" : "", t->rvar.T, t->rvar.J, t->rvar.R,
                       t->d.extra ? ",lds" : t->rvar_tag.fn ? ",tag" : "", RESIDENT_CHUNK, t->d.extra);
     if (t->svar2.fn && t->last_delayed)
-        std::snprintf(inp, sizeof inp, "stream2_kernel<%d,%d%s>", t->svar2.T, t->svar2.J, t->svar2.R ? ",nt" : "");
+        std::snprintf(inp, sizeof inp, "stream2_kernel<%d,%d%s> delay_depth=%d", t->svar2.T, t->svar2.J, t->svar2.R ? ",nt" : "", t->d.delay_depth);
     else if (t->svar.fn)
         std::snprintf(inp, sizeof inp, "%s_kernel<%d,%d%s>", t->sweep ? "sweep" : "stream", t->svar.T, t->svar.J, t->sweep && t->d.sw_nt ? ",nt" : "");
     char str[64];
