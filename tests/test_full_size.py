@@ -37,9 +37,12 @@ def reference(negate):
     return dict(nat=nat, w=w, h=h, m=m, ref=ref, pos=pos, var=var)
 
 
-def test_c5_streaming_kernel_matches_restatement():
-    """One GPU, phase-2 pivots, sweep_kernel (persistent, in place, non-temporal row traffic) that unsharded
-    8194..16385-column tableaux take; the whole 2.1 GB tableau is compared."""
+@pytest.mark.parametrize("delay,kernel", [("1", "stream3_kernel<512,16,nt>"), ("0", "sweep_kernel<512,16,nt>")], ids=["stream3", "sweep"])
+def test_c5_streaming_kernel_matches_restatement(monkeypatch, delay, kernel):
+    """One GPU, phase-2 pivots, through the two persistent in-place kernels that unsharded 8194..16385-column tableaux take --
+    stream3_kernel (the rows get two pivots' eliminations per sweep; the odd budget leaves through the one-pivot flush) and
+    sweep_kernel --, non-temporal row traffic; the whole 2.1 GB tableau is compared."""
+    monkeypatch.setenv("YALPS_HIP_DELAY", delay)
     c5 = reference(negate=False)
     nat, w, h = c5["nat"], c5["w"], c5["h"]
     ctx = nat.Context(0)
@@ -48,7 +51,7 @@ def test_c5_streaming_kernel_matches_restatement():
         ident = np.arange(w + h, dtype=np.int32)
         t.upload(c5["m"], h, ident, ident.copy())
         status, result, npiv, _ = t.solve(max_pivots=MAX_PIVOTS)
-        assert t.info()["last_path"] == "inplace" and t.info()["inplace"] == "sweep_kernel<512,16,nt>", t.info()
+        assert t.info()["last_path"] == "inplace" and t.info()["inplace"] == kernel, t.info()
         got, gpos, gvar = t.download()
     finally:
         t.close()

@@ -853,9 +853,14 @@ def test_degenerate_integer_lps_on_every_path(nat, oracle, monkeypatch, path, en
 
 # ---- sweep_kernel: persistent, in place, for what streams from HBM (8194 .. 16385 columns; 4098 .. 8193 beyond the cache) ----
 SWEEP = [  # M, N, pivots, env, expected kernel, checkCycles
-    (600, 16000, 70, {}, "sweep_kernel<512,16>", False),
-    (300, 9000, 60, {"YALPS_HIP_SWEEP_NT": "1"}, "sweep_kernel<512,16,nt>", False),
-    (2100, 12345, 50, {}, "sweep_kernel<512,16>", False),
+    (600, 16000, 70, {"YALPS_HIP_DELAY": "0"}, "sweep_kernel<512,16>", False),
+    (300, 9000, 60, {"YALPS_HIP_SWEEP_NT": "1", "YALPS_HIP_DELAY": "0"}, "sweep_kernel<512,16,nt>", False),
+    (2100, 12345, 50, {"YALPS_HIP_DELAY": "0"}, "sweep_kernel<512,16>", False),
+    # stream3_kernel (delayed updates for 8194 .. 16385 columns: objective replica in LDS, pending rows in a global scratch)
+    (600, 16000, 71, {"YALPS_HIP_DELAY_MIN_ROWS": "1"}, "stream3_kernel<512,16>", False),
+    (300, 9000, 60, {"YALPS_HIP_SWEEP_NT": "1", "YALPS_HIP_DELAY_MIN_ROWS": "1"}, "stream3_kernel<512,16,nt>", False),
+    (2100, 12345, 51, {"YALPS_HIP_DELAY_DEPTH": "4"}, "stream3_kernel<512,16>", False),
+    (2100, 12345, 7, {"YALPS_HIP_DELAY_DEPTH": "3"}, "stream3_kernel<512,16>", False),
     (1400, 8000, 80, {"YALPS_HIP_SWEEP": "2", "YALPS_HIP_DELAY": "0"}, "sweep_kernel<512,8>", False),
     (2500, 5000, 60, {"YALPS_HIP_SWEEP": "2", "YALPS_HIP_SWEEP_NT": "1", "YALPS_HIP_DELAY": "0"}, "sweep_kernel<512,8,nt>", False),
     (900, 7000, 60, {"YALPS_HIP_SWEEP": "2"}, "sweep_kernel<512,8>", True),
@@ -898,10 +903,13 @@ def test_sweep_kernel_matches_restatement(nat, ctx, monkeypatch, M, N, pivots, e
     assert np.array_equal(got.view(np.int64), ref.view(np.int64))
 
 
+@pytest.mark.parametrize("delay", ["1", "0"], ids=["stream3", "sweep"])
 @pytest.mark.parametrize("kind", ["optimal", "unbounded", "infeasible"])
-def test_sweep_kernel_whole_solves(nat, ctx, oracle, kind):
+def test_sweep_kernel_whole_solves(nat, ctx, oracle, monkeypatch, kind, delay):
     """sweep_kernel to the end of a solve (120 x 9001: few, very wide rows): optimal, unbounded (result = the column) and
     infeasible, against the oracle bit for bit."""
+    monkeypatch.setenv("YALPS_HIP_DELAY", delay)
+    monkeypatch.setenv("YALPS_HIP_DELAY_MIN_ROWS", "1")  # (one row per workgroup here: stream3_kernel by request only)
     M, N = 120, 9000
     w, h = N + 1, M + 1
     m = nat.dense_lp(M, N, 23)
@@ -924,7 +932,7 @@ def test_sweep_kernel_whole_solves(nat, ctx, oracle, kind):
         got, gpos, gvar = t.download()
     finally:
         t.close()
-    assert info["last_path"] == "inplace" and info["inplace"].startswith("sweep_kernel<512,16"), info
+    assert info["last_path"] == "inplace" and info["inplace"].startswith("stream3_kernel<512,16" if delay == "1" else "sweep_kernel<512,16"), info
     assert (status, npiv) == (est, epiv) and G.same_number(result, eres)
     assert np.array_equal(gpos, rpos) and np.array_equal(gvar, rvar)
     assert np.array_equal(got.view(np.int64), ref.view(np.int64))

@@ -1,0 +1,25 @@
+// persistent_stream3.hip -- stream3_kernel variants (see persistent_tables.h)
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cmath>
+#include <cstdint>
+
+#include "../../include/yalps_hip.h"
+#include "persistent_tables.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+#include "common.cuh"
+
+#include "resident_kernel.cuh" // (the sc1 load / store helpers)
+#include "sweep_kernel.cuh" // (the buffer-descriptor row accessors)
+#include "stream3_kernel.cuh"
+// (R = 1: non-temporal row traffic, for tableaux beyond the Infinity Cache)
+#define S3VARIANT(T, J, NT) {T, J, NT, reinterpret_cast<const void *>(&stream3_kernel<T, J, NT != 0>)}
+} // namespace
+PersistentTable yalps_stream3_table() {
+    static const PersistentEntry kStream3[] = {S3VARIANT(512, 16, 0), S3VARIANT(512, 16, 1)};
+    return {kStream3, (int)(sizeof kStream3 / sizeof kStream3[0])};
+}

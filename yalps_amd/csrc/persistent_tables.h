@@ -33,3 +33,5 @@ PersistentTable yalps_stream_table();
 PersistentTable yalps_stream_check_table();
 // stream2_kernel<T, J, NT>: the same with the row updates delayed by one pivot -- two pivots per sweep (stream2_kernel.cuh); R = NT
 PersistentTable yalps_stream2_table();
+// stream3_kernel<T, J, NT>: the same for rows of 8194 .. 16385 columns: objective replica in LDS, pending pivot rows in a global scratch
+PersistentTable yalps_stream3_table();

@@ -1,0 +1,550 @@
+// stream3_kernel.cuh -- stream2_kernel (delayed row updates, several pivots per sweep) for rows too wide for it
+// Part of libyalps_hip.so; included by persistent_stream3.hip inside its unnamed namespace (gfx950 only).
+#pragma once
+
+// ------------------------------------------------------------------------------------------
+// stream3_kernel<T lanes, J units per lane per row, NT>: the same algorithm as stream2_kernel -- a pivot's elimination
+// stays pending, the next decisions are made from scalars, every touched row is streamed once per d.delay_depth pivots and
+// gets all pending eliminations in registers (bit for bit what that many sweeps leave) -- for rows of 8194 .. 16385
+// columns (BASELINE config 5), where neither a lane's 16 units of the objective replica nor two normalised pivot rows of
+// 131 KB fit where stream2_kernel keeps them.  Placement:
+//   * the objective replica lives in LDS (2 T J doubles: every lane reads and writes the columns it also holds of a row);
+//   * the pending normalised pivot rows live in a per-workgroup scratch in global memory (d.pend: [workgroup][depth][pitch],
+//     262-524 KB per workgroup: L2-resident): written when the pivot is decided (plain stores, by the lane that will read
+//     them during the sweep), read 16 bytes per lane, unit and pending pivot during the sweep (L2 traffic as large as the
+//     rows' HBM traffic per pending pivot, which L2 has to spare), single entries for the scalar chains with sc1 loads;
+//   * a pivot row passes through registers 8 units per lane at a time (normalise, objective replica, pricing in one pass).
+// ------------------------------------------------------------------------------------------
+template <int T, int J, bool NT>
+__global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chunk) {
+    __shared__ double sk[2][16];
+    __shared__ int si[2][16];
+    __shared__ double sh_q, sh_c0; // quotient; objective-row entry of the pivot column
+    __shared__ int sh_fail, sh_nt;
+    constexpr int MAXD = 4;
+    __shared__ int sh_pl[MAXD], sh_pc[MAXD]; // the pending pivots, oldest first: my slot of the pivot row (-1: not mine), pivot column (mat index)
+    __shared__ int sh_fast[MAXD][T / 64];       // per wave: nothing of its slice of that pivot row was flushed (:31 select-free path)
+    constexpr int JC = J > 8 ? 8 : J; // units per lane that pass through registers at a time (a pivot row being decided)
+    constexpr int JA = J > 4 ? 4 : J; // ... of a pending pivot row while it is applied to a row in flight
+    extern __shared__ __attribute__((aligned(16))) double sm_dyn[]; // olds[2 T J] (objective replica), colv[depth][rpw], nqv[depth][rpw], lav[rpw], rhsv[rpw], tlist[rpw] (int)
+
+    const int tid = threadIdx.x, NB = d.nb, b = blockIdx.x;
+    const YState *Sin = d.st + parity;
+    YState *Sout = d.st + (parity ^ 1);
+    const YConst *C = d.cst;
+    if (Sin->status != RUNNING) {
+        if (b == 0 && tid == 0) state_copy(Sout, Sin);
+        return;
+    }
+    const int h = C->height, n = d.n, pitch = d.pitch, w = d.w;
+    const double precision = C->precision, max_pivots = C->max_pivots;
+    const int mbuf = Sin->mbuf;
+    double *mat = d.mat[mbuf];
+    double *rhs = d.rhs[mbuf];
+    int phase = Sin->phase;
+    double iter = Sin->iter;
+    int64_t pivots = Sin->pivots;
+    const int64_t hist_len = Sin->hist_len;
+    int slot = 0;
+    const int rpw = (d.hcap + NB - 1) / NB;
+    const int my_rows = b < h ? (h - 1 - b) / NB + 1 : 0;
+    const int depth = d.delay_depth < 1 ? 1 : d.delay_depth > MAXD ? MAXD : d.delay_depth;
+    double *olds = sm_dyn, *colv0 = olds + 2 * T * J, *nqv0 = colv0 + (size_t)depth * rpw, *lav = nqv0 + (size_t)depth * rpw,
+           *rhsv = lav + rpw; // (nqv: what replaces a row's pivot-column entry, :25 / :36 -- one division per row and pivot, by one lane)
+    int *tlist = reinterpret_cast<int *>(rhsv + rpw);
+    const double flushed = __longlong_as_double((long long)FLUSHED);
+    double *prow0 = d.pend + (size_t)b * depth * pitch; // my scratch: the pending normalised pivot rows
+
+    // (rows and scratch rows are addressed through a buffer descriptor of ONE row + a 32-bit lane offset, like sweep_kernel:
+    // flat addressing held a 64-bit pair per unit, pivot and row in flight -- 192 spilled registers)
+    const int lane_off = 16 * tid, row_bytes = pitch * 8;
+    auto rsrc_of = [&](const double *row_ptr) __attribute__((always_inline)) {
+        const unsigned long long a = reinterpret_cast<unsigned long long>(row_ptr);
+        const unsigned long long u = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                                     (unsigned)__builtin_amdgcn_readfirstlane((int)a);
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<double *>(u), 0, row_bytes, 0x00020000);
+    };
+    unsigned padmask = 0; // columns of mine that do not exist (c0 + k >= n): 0.0 in a pivot row, must not count as "flushed"
+#pragma unroll
+    for (int j = 0; j < J; j++)
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+            if (2 * (tid + j * T) + k >= n) padmask |= 1u << (2 * j + k);
+    constexpr unsigned FULL = J == 16 ? 0xFFFFFFFFu : (1u << (2 * (J & 15))) - 1u;
+    // ---- my replica of the objective row (registers), my rows' RHS (LDS) ----
+#pragma unroll
+    for (int j = 0; j < J; j++) *reinterpret_cast<double2 *>(olds + 2 * (tid + j * T)) = row_ld16<AUX_PLAIN>(rsrc_of(mat), lane_off + 16 * T * j, 0);
+    for (int i = tid; i < my_rows; i += T) rhsv[i] = rhs[b + NB * i];
+    if (tid == 0) sh_fail = 0;
+    __syncthreads();
+
+    // ---- the pending pivots (npend of them, [0] the oldest): scalars, pivot rows and my rows' pivot-column entries in LDS ----
+    int npend = 0;
+    // entry (my row slot i, mat column c) after ONE pending pivot, given the entry before it (:14-25, :31-36 for one element)
+    auto after1 = [&](const double *prowp, const double *colvp, const double *nqvp, int lslotp, int colxp, int i, double v, int c)
+                      __attribute__((always_inline)) {
+        const double p = ld_sc1(prowp + c);
+        const bool pnz = (unsigned long long)__double_as_longlong(p) != FLUSHED;
+        const double coef = colvp[i];
+        if (i == lslotp) return c == colxp ? nqvp[i] : (pnz ? p : 0.0);
+        if (fabs(coef) > 1e-16) {
+            if (c == colxp) return nqvp[i];
+            if (pnz) {
+                const double prod = coef * p;
+                return v - prod;
+            }
+        }
+        return v;
+    };
+    // my rows' entries of mat column c as they are NOW (memory + the pending pivots) -> out[]; one barrier
+    auto column_now = [&](int c, double *out) __attribute__((always_inline)) {
+        for (int i = tid; i < my_rows; i += T) {
+            double v = ld_sc1(mat + (size_t)(b + NB * i) * pitch + c);
+            for (int p = 0; p < npend; p++) v = after1(prow0 + (size_t)p * pitch, colv0 + p * rpw, nqv0 + p * rpw, sh_pl[p], sh_pc[p], i, v, c);
+            out[i] = v;
+        }
+        __syncthreads();
+    };
+    // one pending pivot applied to a whole row slice held in registers (the same arithmetic as stream_kernel's finish_row)
+    auto apply_row = [&](const double *prowp, bool is_piv, double coef, double patch, int colxp, bool fastp, double2 (&x)[J])
+                         __attribute__((always_inline)) {
+        const bool act = !is_piv && fabs(coef) > 1e-16; // :31
+        if (!is_piv && !act) return;
+        const __amdgpu_buffer_rsrc_t rsp = rsrc_of(prowp);
+        // (the pivot row's slice comes from my scratch in global memory, JC units per lane at a time: what this lane stored
+        // there when the pivot was decided)
+        if (fastp && !is_piv) { // nothing of this wave's slice was flushed: two fp64 instructions per element, no select
+#pragma unroll
+            for (int jb = 0; jb < J; jb += JA) {
+                double2 pn[JA];
+#pragma unroll
+                for (int j = 0; j < JA; j++) pn[j] = row_ld16<AUX_PLAIN>(rsp, lane_off + 16 * T * (jb + j), 0);
+#pragma unroll
+                for (int j = 0; j < JA; j++) {
+                    const int c0 = 2 * (tid + (jb + j) * T);
+                    if (c0 >= pitch) continue;
+                    const double px = coef * pn[j].x, py = coef * pn[j].y;
+                    x[jb + j].x = x[jb + j].x - px;
+                    x[jb + j].y = x[jb + j].y - py;
+                    if (c0 == (colxp & ~1)) {
+                        if (colxp & 1)
+                            x[jb + j].y = patch;
+                        else
+                            x[jb + j].x = patch;
+                    }
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int jb = 0; jb < J; jb += JA) {
+            double2 pn[JA];
+#pragma unroll
+            for (int j = 0; j < JA; j++) pn[j] = row_ld16<AUX_PLAIN>(rsp, lane_off + 16 * T * (jb + j), 0);
+#pragma unroll
+            for (int j = 0; j < JA; j++) {
+                const int c0 = 2 * (tid + (jb + j) * T);
+                if (c0 >= pitch) continue;
+                const bool f0 = (unsigned long long)__double_as_longlong(pn[j].x) != FLUSHED;
+                const bool f1 = (unsigned long long)__double_as_longlong(pn[j].y) != FLUSHED;
+                if (is_piv) {
+                    x[jb + j].x = f0 ? pn[j].x : 0.0;
+                    x[jb + j].y = f1 ? pn[j].y : 0.0;
+                } else {
+                    const double px = coef * pn[j].x, py = coef * pn[j].y;
+                    const double nx = x[jb + j].x - px, ny = x[jb + j].y - py;
+                    x[jb + j].x = f0 ? nx : x[jb + j].x;
+                    x[jb + j].y = f1 ? ny : x[jb + j].y;
+                }
+                if (c0 == (colxp & ~1)) {
+                    if (colxp & 1)
+                        x[jb + j].y = patch;
+                    else
+                        x[jb + j].x = patch;
+                }
+            }
+        }
+    };
+    // (the pending pivots' wave-uniform scalars are read once per use of apply_pending's caller into registers -- p is a
+    // compile-time index there --; per row and pivot two LDS words remain: the row's coefficient and its patch value.  With
+    // every scalar re-read and -coef/quotient re-divided per row and pivot, by every wave, a row cost 0.85 us per pending
+    // pivot: more than its memory traffic)
+    int pcx[MAXD], pls[MAXD];
+    bool pfast[MAXD];
+    auto pending_scalars = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < MAXD; p++) {
+            pcx[p] = p < npend ? sh_pc[p] : 0;
+            pls[p] = p < npend ? sh_pl[p] : -1;
+            pfast[p] = p < npend ? sh_fast[p][tid >> 6] != 0 : false;
+        }
+    };
+    auto apply_pending = [&](int i, double2 (&x)[J]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < MAXD; p++)
+            if (p < npend) // (uniform)
+                apply_row(prow0 + (size_t)p * pitch, i == pls[p], colv0[p * rpw + i], nqv0[p * rpw + i], pcx[p], pfast[p], x);
+    };
+    auto load_row = [&](int i, double2 (&x)[J]) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rs = rsrc_of(mat + (size_t)(b + NB * i) * pitch);
+#pragma unroll
+        for (int j = 0; j < J; j++) x[j] = row_ld16<NT ? AUX_NT : AUX_PLAIN>(rs, lane_off + 16 * T * j, 0);
+    };
+    auto store_row = [&](int i, const double2 (&x)[J]) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rs = rsrc_of(mat + (size_t)(b + NB * i) * pitch);
+#pragma unroll
+        for (int j = 0; j < J; j++) row_st16<NT ? AUX_NT : AUX_PLAIN>(rs, lane_off + 16 * T * j, 0, x[j]);
+    };
+    // every touched row streamed once, all pending eliminations in registers; afterwards nothing is pending
+    auto flush_pending = [&]() __attribute__((always_inline)) {
+        if (npend == 0) return; // (uniform)
+        if (tid < 64) { // compact list of my touched rows (wave 0)
+            int cnt = 0;
+            for (int base = 0; base < my_rows; base += 64) {
+                const int i = base + tid;
+                bool t = false;
+                if (i < my_rows)
+                    for (int p = 0; p < npend; p++) t = t || i == sh_pl[p] || fabs(colv0[p * rpw + i]) > 1e-16;
+                const unsigned long long m = __ballot(t);
+                if (t) tlist[cnt + __popcll(m & ((1ull << tid) - 1ull))] = i;
+                cnt += __popcll(m);
+            }
+            if (tid == 0) sh_nt = cnt;
+        }
+        __syncthreads();
+        const int nt = sh_nt;
+        pending_scalars();
+        // NBUF row buffers taking turns: NBUF - 1 rows' loads are in flight while one row gets its eliminations and is stored
+        // (a wave's rows are a dependent load -> compute -> store chain each: with one row ahead the sweep ran at the
+        // latency of a row, 2 us, not at the bandwidth of the memory: 4097 x 4097 spent 1.0 us per row and pivot)
+        constexpr int NBUF = J > 8 ? 1 : 2;
+        {
+            double2 xb[NBUF][J];
+#pragma unroll
+            for (int u = 0; u < NBUF - 1; u++)
+                if (u < nt) load_row(tlist[u], xb[u]);
+            for (int k = 0; k < nt; k += NBUF) {
+#pragma unroll
+                for (int u = 0; u < NBUF; u++) {
+                    if (k + u + NBUF - 1 < nt) load_row(tlist[k + u + NBUF - 1], xb[(u + NBUF - 1) % NBUF]);
+                    if (k + u < nt) {
+                        const int i0 = tlist[k + u];
+                        apply_pending(i0, xb[u]);
+                        store_row(i0, xb[u]);
+                    }
+                }
+            }
+        }
+        npend = 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads(); // my rows are complete in memory (and the LDS arrays free) before anything reads them again
+    };
+
+    int la = 0; // entering column of the NEXT pivot (phase 2), priced on my objective replica
+    auto price = [&]() __attribute__((always_inline)) { // src/simplex.ts:71-79
+        KI best = {INFINITY, INT_MAX};
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            const int c0 = 2 * (tid + j * T);
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const double ov = olds[c0 + k];
+                if (c0 + k < n && ov > precision && ki_better(-ov, c0 + k + 1, best.k, best.i)) {
+                    best.k = -ov;
+                    best.i = c0 + k + 1;
+                }
+            }
+        }
+        best = block_argmin<T>(best, sk, si, slot);
+        slot ^= 1;
+        la = best.i == INT_MAX ? 0 : best.i;
+    };
+    // my candidate of the given kind (1 = most negative RHS, 2 = min ratio against lav[]); uniform result
+    auto candidate = [&](int kind) __attribute__((always_inline)) {
+        KI c = {INFINITY, INT_MAX};
+        for (int i = tid; i < my_rows; i += T) {
+            const int r = b + NB * i;
+            if (r < 1) continue;
+            const double my_rhs = rhsv[i];
+            if (kind == 1) {
+                if (my_rhs < -precision && ki_better(my_rhs, r, c.k, c.i)) {
+                    c.k = my_rhs;
+                    c.i = r;
+                }
+            } else if (la > 0) {
+                const double value = lav[i];
+                if (value > precision) {
+                    const double ratio = my_rhs / value;
+                    if (ratio < INFINITY) {
+                        const double key = (ratio <= precision) ? -INFINITY : ratio;
+                        if (ki_better(key, r, c.k, c.i)) {
+                            c.k = key;
+                            c.i = r;
+                        }
+                    }
+                }
+            }
+        }
+        c = block_argmin<T>(c, sk, si, slot);
+        slot ^= 1;
+        return c;
+    };
+    unsigned epoch = 0;
+    // my candidate and its row AS IT IS NOW (memory + pending pivots, in registers; not stored): write-through, drained, flag
+    auto publish = [&](KI cand) __attribute__((always_inline)) {
+        epoch++;
+        const int par = epoch & 1, cg = cand.i == INT_MAX ? 0 : cand.i / NB;
+        if (my_rows > 0) {
+            double2 x[J];
+            const __amdgpu_buffer_rsrc_t rsm = rsrc_of(mat + (size_t)(b + NB * cg) * pitch), rsd = rsrc_of(d.rc_rows[par] + (size_t)b * pitch);
+#pragma unroll
+            for (int j = 0; j < J; j++) x[j] = row_ld16<AUX_PLAIN>(rsm, lane_off + 16 * T * j, 0);
+            pending_scalars();
+            apply_pending(cg, x);
+#pragma unroll
+            for (int j = 0; j < J; j++) row_st16<AUX_SC1>(rsd, lane_off + 16 * T * j, 0, x[j]);
+        }
+        if (tid == 0) st_sc1(d.rc_key[par] + b, rhsv[cg]); // the candidate row's RHS entry
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains ...
+        __syncthreads();                                    // ... before ONE lane raises the flag:
+        if (tid == 0) // ONE 16-byte record {candidate key, epoch << 32 | row}, one store, polled with one 16-byte load
+            st16_sc1(reinterpret_cast<double *>(d.rc_flag[par] + 2 * b),
+                     make_double2(cand.k, __longlong_as_double((long long)(((unsigned long long)epoch << 32) | (unsigned)cand.i))));
+    };
+    int done = 0, term = RUNNING;
+    double term_result = NAN;
+    bool stop = false;
+    auto check = [&]() __attribute__((always_inline)) { // src/simplex.ts:69,109 and :80
+        if (done == chunk) {
+            stop = true;
+        } else if (!(iter < max_pivots)) {
+            term = YALPS_CYCLED;
+            stop = true;
+        } else if (phase == 2 && la == 0) {
+            term = YALPS_OPTIMAL;
+            stop = true;
+        }
+    };
+
+    // first round: candidates from the tableau as loaded
+    price();
+    if (la > 0)
+        column_now(la - 1, lav);
+    else
+        __syncthreads();
+    check();
+    if (!stop) publish(candidate(phase));
+
+    while (!stop) {
+        // ---------------- gather everyone's candidate -------------------------------------------
+        const int par = epoch & 1;
+        KI c = {INFINITY, INT_MAX};
+        if (tid < NB) {
+            unsigned long long f = 0;
+            unsigned spins = 0;
+            unsigned long long spin_t0 = 0;
+            double2 rec;
+            for (;;) {
+                rec = ld16_sc1_one(d.rc_flag[par] + 2 * tid);
+                f = (unsigned long long)__double_as_longlong(rec.y);
+                if ((unsigned)(f >> 32) == epoch) break;
+                if (spin_expired(spins, spin_t0, d.rc_err)) {
+                    sh_fail = 1;
+                    __hip_atomic_store(d.rc_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            c.i = (int)(unsigned)f;
+            c.k = rec.x;
+        }
+        c = block_argmin<T>(c, sk, si, slot); // (its barrier is the one the polling waves join)
+        slot ^= 1;
+        if (sh_fail) return; // uniform: written before the barrier above
+        if (c.i == INT_MAX) {
+            if (phase == 1) { // :120 phase 1 is over: same tableau, now the min-ratio exchange
+                phase = 2;
+                iter = 0.0;
+                check();
+                if (!stop) {
+                    if (la > 0)
+                        column_now(la - 1, lav);
+                    else
+                        __syncthreads();
+                    publish(candidate(2));
+                }
+            } else {
+                term = YALPS_UNBOUNDED; // :96
+                term_result = (double)la;
+                stop = true;
+            }
+            continue;
+        }
+        const int row_in = c.i, row = (unsigned)row_in < (unsigned)h ? row_in : 0, owner = row % NB;
+        if (row != row_in && tid == 0) __hip_atomic_store(d.rc_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (never expected)
+        const int lslot = owner == b ? row / NB : -1; // my slot of the pivot row, if I own it
+        // ---------------- the winner's row as published: the tableau's row after every earlier pivot ----------------
+        const double *src = d.rc_rows[par] + (size_t)owner * pitch;
+        const double rhs_row = ld_sc1(d.rc_key[par] + owner);
+        const __amdgpu_buffer_rsrc_t rsrc_src = rsrc_of(src);
+        int col = la;
+        if (phase == 1) { // :123-134, JC units of the raw row per lane at a time
+            KI e = {INFINITY, INT_MAX};
+#pragma unroll
+            for (int jb = 0; jb < J; jb += JC) {
+                double2 pv[JC];
+#pragma unroll
+                for (int j = 0; j < JC; j++) pv[j] = row_ld16<AUX_SC1>(rsrc_src, lane_off + 16 * T * (jb + j), 0);
+#pragma unroll
+                for (int j = 0; j < JC; j++) {
+                    const int c0 = 2 * (tid + (jb + j) * T);
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        const double coefficient = elem(pv[j], k);
+                        if (c0 + k < n && coefficient < -precision) {
+                            const double ratio = -olds[c0 + k] / coefficient;
+                            if (ratio > -INFINITY && ki_better(-ratio, c0 + k + 1, e.k, e.i)) {
+                                e.k = -ratio;
+                                e.i = c0 + k + 1;
+                            }
+                        }
+                    }
+                }
+            }
+            e = block_argmin<T>(e, sk, si, slot);
+            slot ^= 1;
+            if (e.i == INT_MAX) { // :135
+                term = YALPS_INFEASIBLE;
+                stop = true;
+                continue;
+            }
+            col = e.i;
+        }
+        // ---------------- pivot (src/simplex.ts:5-39): it becomes pending pivot number npend ---------------------------
+        const int colx = col - 1;
+        double *prowN = prow0 + (size_t)npend * pitch, *colvN = colv0 + npend * rpw, *nqvN = nqv0 + npend * rpw;
+        // my rows' pivot-column entries as they are now, the quotient, the objective row's entry (LDS: complete since
+        // price()'s barrier of the previous pivot)
+        if (phase == 2) {
+            for (int i = tid; i < my_rows; i += T) colvN[i] = lav[i];
+            __syncthreads();
+        } else {
+            column_now(colx, colvN);
+        }
+        const double q = ld_sc1(src + colx), coef0 = olds[colx], inv_q = 1.0 / q;
+        __syncthreads(); // (everybody has read olds[colx] before its owner patches it below)
+        const bool nz_rhs = fabs(rhs_row) > 1e-16;
+        const double pn_rhs = nz_rhs ? rhs_row / q : 0.0;
+        for (int i = tid; i < my_rows; i += T) { // RHS entries of my rows (:33 at column 0)
+            const double coef = colvN[i];
+            if (i == lslot)
+                rhsv[i] = pn_rhs;
+            else if (fabs(coef) > 1e-16 && nz_rhs) {
+                const double prod = coef * pn_rhs;
+                rhsv[i] = rhsv[i] - prod;
+            }
+            nqvN[i] = i == lslot ? inv_q : -coef / q; // what replaces the pivot column (:25, :36)
+        }
+        // one pass over the raw row, JC units per lane at a time: normalised -> my scratch (:14-25; FLUSHED marks what pivot()
+        // zeroed), my objective replica updated (:27-38 for row 0), and priced (:71-79) while it is in registers
+        const bool touched0 = fabs(coef0) > 1e-16;
+        const double nq0 = -coef0 / q; // :36 for the objective row
+        const __amdgpu_buffer_rsrc_t rsrc_new = rsrc_of(prowN);
+        unsigned nzmask = 0;
+        KI best = {INFINITY, INT_MAX};
+#pragma unroll
+        for (int jb = 0; jb < J; jb += JC) {
+            double2 pv[JC];
+#pragma unroll
+            for (int j = 0; j < JC; j++) pv[j] = row_ld16<AUX_SC1>(rsrc_src, lane_off + 16 * T * (jb + j), 0);
+#pragma unroll
+            for (int j = 0; j < JC; j++) {
+                const int c0 = 2 * (tid + (jb + j) * T);
+                double2 pn, ov = *reinterpret_cast<const double2 *>(olds + c0);
+                bool nzk[2];
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const double v = elem(pv[j], k);
+                    nzk[k] = fabs(v) > 1e-16;
+                    const double vn = nzk[k] ? v / q : 0.0;
+                    pn = with_elem(pn, k, nzk[k] ? vn : flushed);
+                    if (nzk[k]) nzmask |= 1u << (2 * (jb + j) + k);
+                    double o1 = elem(ov, k);
+                    if (touched0) {
+                        if (c0 + k == colx)
+                            o1 = nq0;
+                        else if (nzk[k]) {
+                            const double prod = coef0 * vn;
+                            o1 = o1 - prod;
+                        }
+                    }
+                    ov = with_elem(ov, k, o1);
+                    if (c0 + k < n && o1 > precision && ki_better(-o1, c0 + k + 1, best.k, best.i)) {
+                        best.k = -o1;
+                        best.i = c0 + k + 1;
+                    }
+                }
+                *reinterpret_cast<double2 *>(olds + c0) = ov;
+                row_st16<AUX_PLAIN>(rsrc_new, lane_off + 16 * T * (jb + j), 0, pn);
+            }
+        }
+        {
+            const bool fast = __builtin_amdgcn_ballot_w64(((nzmask | padmask) & FULL) != FULL) == 0; // (per wave)
+            if ((tid & 63) == 0) sh_fast[npend][tid >> 6] = fast ? 1 : 0;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (my scratch stores are out before the barrier below: other waves' scalar chains read them at L2)
+        if (tid == 0) { // (published to the workgroup by price()'s barrier, like prow / rhsv)
+            sh_pl[npend] = lslot;
+            sh_pc[npend] = colx;
+        }
+        npend += 1;
+        iter += 1.0;
+        pivots += 1;
+        done += 1;
+        best = block_argmin<T>(best, sk, si, slot); // la of the next pivot (its barrier also publishes the scratch row / rhsv / the pending scalars)
+        slot ^= 1;
+        la = best.i == INT_MAX ? 0 : best.i;
+        check();
+        if (!stop) {
+            if (phase == 2) column_now(la - 1, lav); // my rows' entries of column la after every pivot so far
+            publish(candidate(phase));               // (la > 0 here: check() stops phase 2 without an entering column)
+        }
+        if (b == 0 && tid == 0) { // basis bookkeeping, :7-12 (off the critical path)
+            const int leaving = d.var[w + row], entering = d.var[col];
+            d.var[w + row] = entering;
+            d.var[col] = leaving;
+            d.pos[leaving] = col;
+            d.pos[entering] = w + row;
+        }
+        // ---------------- the rows: only every depth-th pivot (or on the way out) ----------------------------------------
+        if (npend == depth || stop)
+            flush_pending();
+        else
+            __syncthreads(); // (colv / rhsv / lav of this pivot are complete before the next round's lanes read them)
+    }
+    flush_pending(); // (a pivot decided before a break out of the loop: unbounded / infeasible leave with one pending)
+
+    // ---------------- leave: RHS column, state (the rows are where they were) --------------------
+    for (int i = tid; i < my_rows; i += T) rhs[b + NB * i] = rhsv[i];
+    if (b == 0 && tid == 0) {
+        if (term == YALPS_OPTIMAL) term_result = round_to_precision(rhsv[0], precision);
+        Sout->status = term;
+        Sout->phase = phase;
+        Sout->bootstrap = 1; // the launch-per-pivot kernels would have to re-scan
+        Sout->la = 0;
+        Sout->pbuf = 0;
+        Sout->mbuf = mbuf;
+        Sout->pause = 0;
+        Sout->dec_valid = 0;
+        Sout->dec_row = 0;
+        Sout->dec_col = 0;
+        Sout->swap_valid = 0;
+        Sout->swap_row = 0;
+        Sout->swap_col = 0;
+        Sout->pad_ = 0;
+        Sout->hist_len = hist_len;
+        Sout->iter = iter;
+        Sout->result = term_result;
+        Sout->pivots = pivots;
+    }
+}

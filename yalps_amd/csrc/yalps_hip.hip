@@ -141,6 +141,7 @@ const std::vector<RVariant> kStreamCheck = variants_of({yalps_stream_check_table
 const std::vector<RVariant> kSweep = variants_of({yalps_sweep_table()});
 const std::vector<RVariant> kSweepCheck = variants_of({yalps_sweep_check_table()});
 const std::vector<RVariant> kStream2 = variants_of({yalps_stream2_table()}); // (R = non-temporal row traffic)
+const std::vector<RVariant> kStream3 = variants_of({yalps_stream3_table()});
 constexpr size_t SWEEP_BEYOND_CACHE = 200u << 20; // tableau bytes from which row traffic goes non-temporal (Infinity Cache: 256 MiB)
 constexpr int RESIDENT_CHUNK = 4096; // pivots per launch of the resident kernel (bounds its run time)
 
@@ -274,6 +275,7 @@ struct yalps_tableau {
     size_t sshmem2 = 0;
     bool sattr2 = false;
     bool last_delayed = true; // what the last in-place solve ran (before the first one: what it would run)
+    bool stream3 = false;     // svar2 is a stream3_kernel variant (rows of 8194 .. 16385 columns)
     bool sattr_check = false;
     size_t sshmem = 0;
     bool sattr = false;
@@ -707,6 +709,25 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
                     t->sshmem = lds;
                     d.sw_nt = want_nt;
                 }
+                // rows of 8194 .. 16385 columns with delayed updates: stream3_kernel (objective replica in LDS, the pending
+                // pivot rows in a per-workgroup scratch in global memory), as many pivots per sweep as YALPS_HIP_DELAY_DEPTH says
+                // (measured: 16385 x 16385 738 -> 480 us per pivot at depth 4, 4097 x 16385 189 -> 148; with few rows per
+                // workgroup the longer head of its pivots loses: 1025 x 16385 50 -> 64 us, those stay with sweep_kernel)
+                if (t->sweep && J == 8 && env_int("YALPS_HIP_DELAY", 1) && rows_per_block >= env_int("YALPS_HIP_DELAY_MIN_ROWS", 8)) {
+                    const int depth = std::min(4, std::max(1, env_int("YALPS_HIP_DELAY_DEPTH", 4)));
+                    const size_t lds3 = sizeof(double) * (2 * 512 * 16 + (2 * (size_t)depth + 2) * (size_t)rows_per_block) +
+                                        sizeof(int32_t) * (size_t)rows_per_block;
+                    if (depth >= 2 && lds3 <= 150 * 1024) {
+                        for (const RVariant &v : kStream3)
+                            if (v.T == 512 && v.J == 16 && v.R == want_nt) t->svar2 = v;
+                        if (t->svar2.fn) {
+                            t->sshmem2 = lds3;
+                            d.delay_depth = depth;
+                            HIP_TRY(hipMalloc(&d.pend, sizeof(double) * (size_t)t->nb * depth * d.pitch));
+                            t->stream3 = true;
+                        }
+                    }
+                }
             }
         }
     }
@@ -788,7 +809,7 @@ void yalps_tableau_destroy(yalps_tableau *t) {
     void *bufs[] = {d.mat[0], d.mat[1], d.rhs[0], d.rhs[1], t->perm_block ? nullptr : d.pos, t->perm_block ? nullptr : d.var, t->perm_block,
                     t->ctl_block ? nullptr : d.st, t->ctl_block ? nullptr : d.cst, t->ctl_block, d.rc_rows[0], d.rc_rows[1], t->perm_backup,
                     d.rc_key[0], d.rc_key[1], d.gen_prow, d.gen_scal, d.part_ratio[0], d.part_ratio[1], d.part_rhs[0], d.part_rhs[1],
-                    t->hist[0], t->hist[1], t->cells, d.dbg, d.obj[0]};
+                    t->hist[0], t->hist[1], t->cells, d.dbg, d.obj[0], d.pend};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (t->host_state) (void)hipHostFree(t->host_state);
@@ -808,7 +829,7 @@ int32_t yalps_tableau_info(const yalps_tableau *t, char *buf, int32_t len) {
         std::snprintf(res, sizeof res, "resident%s_kernel<%d,%d,%d%s> chunk=%d lds_rows=%d", t->rgen == 2 && !t->rvar_tag.fn ? "2" : "", t->rvar.T, t->rvar.J, t->rvar.R,
                       t->d.extra ? ",lds" : t->rvar_tag.fn ? ",tag" : "", RESIDENT_CHUNK, t->d.extra);
     if (t->svar2.fn && t->last_delayed)
-        std::snprintf(inp, sizeof inp, "stream2_kernel<%d,%d%s> delay_depth=%d", t->svar2.T, t->svar2.J, t->svar2.R ? ",nt" : "", t->d.delay_depth);
+        std::snprintf(inp, sizeof inp, "stream%d_kernel<%d,%d%s> delay_depth=%d", t->stream3 ? 3 : 2, t->svar2.T, t->svar2.J, t->svar2.R ? ",nt" : "", t->d.delay_depth);
     else if (t->svar.fn)
         std::snprintf(inp, sizeof inp, "%s_kernel<%d,%d%s>", t->sweep ? "sweep" : "stream", t->svar.T, t->svar.J, t->sweep && t->d.sw_nt ? ",nt" : "");
     char str[64];
