@@ -25,7 +25,7 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
     __shared__ int sh_pl[MAXD], sh_pc[MAXD]; // the pending pivots, oldest first: my slot of the pivot row (-1: not mine), pivot column (mat index)
     __shared__ int sh_fast[MAXD][T / 64];       // per wave: nothing of its slice of that pivot row was flushed (:31 select-free path)
     constexpr int JC = J > 8 ? 8 : J; // units per lane that pass through registers at a time (a pivot row being decided)
-    constexpr int JA = J > 4 ? 4 : J; // ... of a pending pivot row while it is applied to a row in flight
+    constexpr int JA = J > 2 ? 2 : J; // ... of a pending pivot row while it is applied to the rows in flight
     extern __shared__ __attribute__((aligned(16))) double sm_dyn[]; // olds[2 T J] (objective replica), colv[depth][rpw], nqv[depth][rpw], lav[rpw], rhsv[rpw], tlist[rpw] (int)
 
     const int tid = threadIdx.x, NB = d.nb, b = blockIdx.x;
@@ -98,72 +98,14 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
     };
     // my rows' entries of mat column c as they are NOW (memory + the pending pivots) -> out[]; one barrier
     auto column_now = [&](int c, double *out) __attribute__((always_inline)) {
-        for (int i = tid; i < my_rows; i += T) {
+        int t0 = tid;
+        asm volatile("" : "+v"(t0)); // (opaque: my rows' base addresses are recomputed here, not hoisted out of the pivot loop and spilled)
+        for (int i = t0; i < my_rows; i += T) {
             double v = ld_sc1(mat + (size_t)(b + NB * i) * pitch + c);
             for (int p = 0; p < npend; p++) v = after1(prow0 + (size_t)p * pitch, colv0 + p * rpw, nqv0 + p * rpw, sh_pl[p], sh_pc[p], i, v, c);
             out[i] = v;
         }
         __syncthreads();
-    };
-    // one pending pivot applied to a whole row slice held in registers (the same arithmetic as stream_kernel's finish_row)
-    auto apply_row = [&](const double *prowp, bool is_piv, double coef, double patch, int colxp, bool fastp, double2 (&x)[J])
-                         __attribute__((always_inline)) {
-        const bool act = !is_piv && fabs(coef) > 1e-16; // :31
-        if (!is_piv && !act) return;
-        const __amdgpu_buffer_rsrc_t rsp = rsrc_of(prowp);
-        // (the pivot row's slice comes from my scratch in global memory, JC units per lane at a time: what this lane stored
-        // there when the pivot was decided)
-        if (fastp && !is_piv) { // nothing of this wave's slice was flushed: two fp64 instructions per element, no select
-#pragma unroll
-            for (int jb = 0; jb < J; jb += JA) {
-                double2 pn[JA];
-#pragma unroll
-                for (int j = 0; j < JA; j++) pn[j] = row_ld16<AUX_PLAIN>(rsp, lane_off + 16 * T * (jb + j), 0);
-#pragma unroll
-                for (int j = 0; j < JA; j++) {
-                    const int c0 = 2 * (tid + (jb + j) * T);
-                    if (c0 >= pitch) continue;
-                    const double px = coef * pn[j].x, py = coef * pn[j].y;
-                    x[jb + j].x = x[jb + j].x - px;
-                    x[jb + j].y = x[jb + j].y - py;
-                    if (c0 == (colxp & ~1)) {
-                        if (colxp & 1)
-                            x[jb + j].y = patch;
-                        else
-                            x[jb + j].x = patch;
-                    }
-                }
-            }
-            return;
-        }
-#pragma unroll
-        for (int jb = 0; jb < J; jb += JA) {
-            double2 pn[JA];
-#pragma unroll
-            for (int j = 0; j < JA; j++) pn[j] = row_ld16<AUX_PLAIN>(rsp, lane_off + 16 * T * (jb + j), 0);
-#pragma unroll
-            for (int j = 0; j < JA; j++) {
-                const int c0 = 2 * (tid + (jb + j) * T);
-                if (c0 >= pitch) continue;
-                const bool f0 = (unsigned long long)__double_as_longlong(pn[j].x) != FLUSHED;
-                const bool f1 = (unsigned long long)__double_as_longlong(pn[j].y) != FLUSHED;
-                if (is_piv) {
-                    x[jb + j].x = f0 ? pn[j].x : 0.0;
-                    x[jb + j].y = f1 ? pn[j].y : 0.0;
-                } else {
-                    const double px = coef * pn[j].x, py = coef * pn[j].y;
-                    const double nx = x[jb + j].x - px, ny = x[jb + j].y - py;
-                    x[jb + j].x = f0 ? nx : x[jb + j].x;
-                    x[jb + j].y = f1 ? ny : x[jb + j].y;
-                }
-                if (c0 == (colxp & ~1)) {
-                    if (colxp & 1)
-                        x[jb + j].y = patch;
-                    else
-                        x[jb + j].x = patch;
-                }
-            }
-        }
     };
     // (the pending pivots' wave-uniform scalars are read once per use of apply_pending's caller into registers -- p is a
     // compile-time index there --; per row and pivot two LDS words remain: the row's coefficient and its patch value.  With
@@ -179,21 +121,63 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
             pfast[p] = p < npend ? sh_fast[p][tid >> 6] != 0 : false;
         }
     };
-    auto apply_pending = [&](int i, double2 (&x)[J]) __attribute__((always_inline)) {
+    // the pending pivots applied to (up to) RB half-rows held in registers: units [u0, u0 + JH) of my row slots ri[0 .. cnt)
+    constexpr int JH = J > 8 ? 8 : J, RB = 2;
+    auto apply_batch = [&](int u0, double2 (&xb)[RB][JH], const int (&ri)[RB], int cnt) __attribute__((always_inline)) {
 #pragma unroll
-        for (int p = 0; p < MAXD; p++)
-            if (p < npend) // (uniform)
-                apply_row(prow0 + (size_t)p * pitch, i == pls[p], colv0[p * rpw + i], nqv0[p * rpw + i], pcx[p], pfast[p], x);
-    };
-    auto load_row = [&](int i, double2 (&x)[J]) __attribute__((always_inline)) {
-        const __amdgpu_buffer_rsrc_t rs = rsrc_of(mat + (size_t)(b + NB * i) * pitch);
+        for (int p = 0; p < MAXD; p++) {
+            if (p >= npend) continue; // (uniform)
+            const __amdgpu_buffer_rsrc_t rsp = rsrc_of(prow0 + (size_t)p * pitch);
+            const int colxp = pcx[p];
+            const bool fastp = pfast[p];
+            double coefu[RB], patchu[RB];
+            bool pivu[RB], actu[RB];
 #pragma unroll
-        for (int j = 0; j < J; j++) x[j] = row_ld16<NT ? AUX_NT : AUX_PLAIN>(rs, lane_off + 16 * T * j, 0);
-    };
-    auto store_row = [&](int i, const double2 (&x)[J]) __attribute__((always_inline)) {
-        const __amdgpu_buffer_rsrc_t rs = rsrc_of(mat + (size_t)(b + NB * i) * pitch);
+            for (int u = 0; u < RB; u++) {
+                coefu[u] = colv0[p * rpw + ri[u]];
+                patchu[u] = nqv0[p * rpw + ri[u]];
+                pivu[u] = ri[u] == pls[p];
+                actu[u] = u < cnt && (pivu[u] || fabs(coefu[u]) > 1e-16); // :31
+            }
 #pragma unroll
-        for (int j = 0; j < J; j++) row_st16<NT ? AUX_NT : AUX_PLAIN>(rs, lane_off + 16 * T * j, 0, x[j]);
+            for (int jb = 0; jb < JH; jb += JA) {
+                double2 pn[JA];
+#pragma unroll
+                for (int j = 0; j < JA; j++) pn[j] = row_ld16<AUX_PLAIN>(rsp, lane_off + 16 * T * (u0 + jb + j), 0);
+#pragma unroll
+                for (int u = 0; u < RB; u++) {
+                    if (!actu[u]) continue; // (uniform)
+#pragma unroll
+                    for (int j = 0; j < JA; j++) {
+                        const int c0 = 2 * (tid + (u0 + jb + j) * T);
+                        double2 &xv = xb[u][jb + j];
+                        if (fastp && !pivu[u]) {
+                            const double px = coefu[u] * pn[j].x, py = coefu[u] * pn[j].y;
+                            xv.x = xv.x - px;
+                            xv.y = xv.y - py;
+                        } else {
+                            const bool f0 = (unsigned long long)__double_as_longlong(pn[j].x) != FLUSHED;
+                            const bool f1 = (unsigned long long)__double_as_longlong(pn[j].y) != FLUSHED;
+                            if (pivu[u]) {
+                                xv.x = f0 ? pn[j].x : 0.0;
+                                xv.y = f1 ? pn[j].y : 0.0;
+                            } else {
+                                const double px = coefu[u] * pn[j].x, py = coefu[u] * pn[j].y;
+                                const double nx = xv.x - px, ny = xv.y - py;
+                                xv.x = f0 ? nx : xv.x;
+                                xv.y = f1 ? ny : xv.y;
+                            }
+                        }
+                        if (c0 == (colxp & ~1)) {
+                            if (colxp & 1)
+                                xv.y = patchu[u];
+                            else
+                                xv.x = patchu[u];
+                        }
+                    }
+                }
+            }
+        }
     };
     // every touched row streamed once, all pending eliminations in registers; afterwards nothing is pending
     auto flush_pending = [&]() __attribute__((always_inline)) {
@@ -214,23 +198,31 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
         __syncthreads();
         const int nt = sh_nt;
         pending_scalars();
-        // NBUF row buffers taking turns: NBUF - 1 rows' loads are in flight while one row gets its eliminations and is stored
-        // (a wave's rows are a dependent load -> compute -> store chain each: with one row ahead the sweep ran at the
-        // latency of a row, 2 us, not at the bandwidth of the memory: 4097 x 4097 spent 1.0 us per row and pivot)
-        constexpr int NBUF = J > 8 ? 1 : 2;
-        {
-            double2 xb[NBUF][J];
+        // The rows in column halves (JH units per lane), RB rows at a time: a chunk of a pending pivot row is read ONCE from my
+        // scratch (L2) and applied to the RB half-rows in registers.  (Row by row the scratch reads were as many bytes per
+        // pending pivot as the rows' own HBM traffic: 2 GB of L2 reads per pivot at 16385 x 16385, ~250 us of a 480 us pivot.)
+#pragma unroll 1
+        for (int u0 = 0; u0 < J; u0 += JH) {
+#pragma unroll 1
+            for (int k = 0; k < nt; k += RB) {
+                double2 xb[RB][JH];
+                int ri[RB];
 #pragma unroll
-            for (int u = 0; u < NBUF - 1; u++)
-                if (u < nt) load_row(tlist[u], xb[u]);
-            for (int k = 0; k < nt; k += NBUF) {
-#pragma unroll
-                for (int u = 0; u < NBUF; u++) {
-                    if (k + u + NBUF - 1 < nt) load_row(tlist[k + u + NBUF - 1], xb[(u + NBUF - 1) % NBUF]);
+                for (int u = 0; u < RB; u++) {
+                    ri[u] = tlist[k + u < nt ? k + u : k];
+                    const __amdgpu_buffer_rsrc_t rs = rsrc_of(mat + (size_t)(b + NB * ri[u]) * pitch);
                     if (k + u < nt) {
-                        const int i0 = tlist[k + u];
-                        apply_pending(i0, xb[u]);
-                        store_row(i0, xb[u]);
+#pragma unroll
+                        for (int j = 0; j < JH; j++) xb[u][j] = row_ld16<NT ? AUX_NT : AUX_PLAIN>(rs, lane_off + 16 * T * (u0 + j), 0);
+                    }
+                }
+                apply_batch(u0, xb, ri, nt - k);
+#pragma unroll
+                for (int u = 0; u < RB; u++) {
+                    if (k + u < nt) {
+                        const __amdgpu_buffer_rsrc_t rs = rsrc_of(mat + (size_t)(b + NB * ri[u]) * pitch);
+#pragma unroll
+                        for (int j = 0; j < JH; j++) row_st16<NT ? AUX_NT : AUX_PLAIN>(rs, lane_off + 16 * T * (u0 + j), 0, xb[u][j]);
                     }
                 }
             }
@@ -295,14 +287,20 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
         epoch++;
         const int par = epoch & 1, cg = cand.i == INT_MAX ? 0 : cand.i / NB;
         if (my_rows > 0) {
-            double2 x[J];
             const __amdgpu_buffer_rsrc_t rsm = rsrc_of(mat + (size_t)(b + NB * cg) * pitch), rsd = rsrc_of(d.rc_rows[par] + (size_t)b * pitch);
-#pragma unroll
-            for (int j = 0; j < J; j++) x[j] = row_ld16<AUX_PLAIN>(rsm, lane_off + 16 * T * j, 0);
             pending_scalars();
-            apply_pending(cg, x);
+#pragma unroll 1
+            for (int u0 = 0; u0 < J; u0 += JH) {
+                double2 xb[RB][JH];
+                int ri[RB];
 #pragma unroll
-            for (int j = 0; j < J; j++) row_st16<AUX_SC1>(rsd, lane_off + 16 * T * j, 0, x[j]);
+                for (int u = 0; u < RB; u++) ri[u] = cg;
+#pragma unroll
+                for (int j = 0; j < JH; j++) xb[0][j] = row_ld16<AUX_PLAIN>(rsm, lane_off + 16 * T * (u0 + j), 0);
+                apply_batch(u0, xb, ri, 1);
+#pragma unroll
+                for (int j = 0; j < JH; j++) row_st16<AUX_SC1>(rsd, lane_off + 16 * T * (u0 + j), 0, xb[0][j]);
+            }
         }
         if (tid == 0) st_sc1(d.rc_key[par] + b, rhsv[cg]); // the candidate row's RHS entry
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains ...
