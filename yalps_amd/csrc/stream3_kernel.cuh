@@ -21,7 +21,7 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
     __shared__ int si[2][16];
     __shared__ double sh_q, sh_c0; // quotient; objective-row entry of the pivot column
     __shared__ int sh_fail, sh_nt;
-    constexpr int MAXD = 4;
+    constexpr int MAXD = 8;
     __shared__ int sh_pl[MAXD], sh_pc[MAXD]; // the pending pivots, oldest first: my slot of the pivot row (-1: not mine), pivot column (mat index)
     __shared__ int sh_fast[MAXD][T / 64];       // per wave: nothing of its slice of that pivot row was flushed (:31 select-free path)
     constexpr int JC = J > 8 ? 8 : J; // units per lane that pass through registers at a time (a pivot row being decided)
@@ -81,9 +81,8 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
     // ---- the pending pivots (npend of them, [0] the oldest): scalars, pivot rows and my rows' pivot-column entries in LDS ----
     int npend = 0;
     // entry (my row slot i, mat column c) after ONE pending pivot, given the entry before it (:14-25, :31-36 for one element)
-    auto after1 = [&](const double *prowp, const double *colvp, const double *nqvp, int lslotp, int colxp, int i, double v, int c)
+    auto after1 = [&](double p, const double *colvp, const double *nqvp, int lslotp, int colxp, int i, double v, int c)
                       __attribute__((always_inline)) {
-        const double p = ld_sc1(prowp + c);
         const bool pnz = (unsigned long long)__double_as_longlong(p) != FLUSHED;
         const double coef = colvp[i];
         if (i == lslotp) return c == colxp ? nqvp[i] : (pnz ? p : 0.0);
@@ -101,42 +100,35 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
         int t0 = tid;
         asm volatile("" : "+v"(t0)); // (opaque: my rows' base addresses are recomputed here, not hoisted out of the pivot loop and spilled)
         for (int i = t0; i < my_rows; i += T) {
-            double v = ld_sc1(mat + (size_t)(b + NB * i) * pitch + c);
-            for (int p = 0; p < npend; p++) v = after1(prow0 + (size_t)p * pitch, colv0 + p * rpw, nqv0 + p * rpw, sh_pl[p], sh_pc[p], i, v, c);
+            // (the entry and the pending pivot rows' entries of that column: all loads in flight at once -- one after the
+            // other they were a dependent trip through L2 per pending pivot on every pivot's chain)
+            double pe[MAXD];
+            double v = __hip_atomic_load(mat + (size_t)(b + NB * i) * pitch + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int p = 0; p < MAXD; p++)
+                pe[p] = p < npend ? __hip_atomic_load(prow0 + (size_t)p * pitch + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+#pragma unroll
+            for (int p = 0; p < MAXD; p++)
+                if (p < npend) v = after1(pe[p], colv0 + p * rpw, nqv0 + p * rpw, sh_pl[p], sh_pc[p], i, v, c);
             out[i] = v;
         }
         __syncthreads();
     };
-    // (the pending pivots' wave-uniform scalars are read once per use of apply_pending's caller into registers -- p is a
-    // compile-time index there --; per row and pivot two LDS words remain: the row's coefficient and its patch value.  With
-    // every scalar re-read and -coef/quotient re-divided per row and pivot, by every wave, a row cost 0.85 us per pending
-    // pivot: more than its memory traffic)
-    int pcx[MAXD], pls[MAXD];
-    bool pfast[MAXD];
-    auto pending_scalars = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int p = 0; p < MAXD; p++) {
-            pcx[p] = p < npend ? sh_pc[p] : 0;
-            pls[p] = p < npend ? sh_pl[p] : -1;
-            pfast[p] = p < npend ? sh_fast[p][tid >> 6] != 0 : false;
-        }
-    };
     // the pending pivots applied to (up to) RB half-rows held in registers: units [u0, u0 + JH) of my row slots ri[0 .. cnt)
     constexpr int JH = J > 8 ? 8 : J, RB = 2;
     auto apply_batch = [&](int u0, double2 (&xb)[RB][JH], const int (&ri)[RB], int cnt) __attribute__((always_inline)) {
-#pragma unroll
-        for (int p = 0; p < MAXD; p++) {
-            if (p >= npend) continue; // (uniform)
+#pragma unroll 1
+        for (int p = 0; p < npend; p++) { // (a run-time loop: its scalars are read once per batch of RB half-rows)
             const __amdgpu_buffer_rsrc_t rsp = rsrc_of(prow0 + (size_t)p * pitch);
-            const int colxp = pcx[p];
-            const bool fastp = pfast[p];
+            const int colxp = sh_pc[p], lslotp = sh_pl[p];
+            const bool fastp = sh_fast[p][tid >> 6] != 0;
             double coefu[RB], patchu[RB];
             bool pivu[RB], actu[RB];
 #pragma unroll
             for (int u = 0; u < RB; u++) {
                 coefu[u] = colv0[p * rpw + ri[u]];
                 patchu[u] = nqv0[p * rpw + ri[u]];
-                pivu[u] = ri[u] == pls[p];
+                pivu[u] = ri[u] == lslotp;
                 actu[u] = u < cnt && (pivu[u] || fabs(coefu[u]) > 1e-16); // :31
             }
 #pragma unroll
@@ -197,7 +189,6 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
         }
         __syncthreads();
         const int nt = sh_nt;
-        pending_scalars();
         // The rows in column halves (JH units per lane), RB rows at a time: a chunk of a pending pivot row is read ONCE from my
         // scratch (L2) and applied to the RB half-rows in registers.  (Row by row the scratch reads were as many bytes per
         // pending pivot as the rows' own HBM traffic: 2 GB of L2 reads per pivot at 16385 x 16385, ~250 us of a 480 us pivot.)
@@ -288,8 +279,7 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
         const int par = epoch & 1, cg = cand.i == INT_MAX ? 0 : cand.i / NB;
         if (my_rows > 0) {
             const __amdgpu_buffer_rsrc_t rsm = rsrc_of(mat + (size_t)(b + NB * cg) * pitch), rsd = rsrc_of(d.rc_rows[par] + (size_t)b * pitch);
-            pending_scalars();
-#pragma unroll 1
+    #pragma unroll 1
             for (int u0 = 0; u0 < J; u0 += JH) {
                 double2 xb[RB][JH];
                 int ri[RB];

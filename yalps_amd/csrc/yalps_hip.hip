@@ -714,7 +714,10 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
                 // (measured: 16385 x 16385 738 -> 480 us per pivot at depth 4, 4097 x 16385 189 -> 148; with few rows per
                 // workgroup the longer head of its pivots loses: 1025 x 16385 50 -> 64 us, those stay with sweep_kernel)
                 if (t->sweep && J == 8 && env_int("YALPS_HIP_DELAY", 1) && rows_per_block >= env_int("YALPS_HIP_DELAY_MIN_ROWS", 8)) {
-                    const int depth = std::min(4, std::max(1, env_int("YALPS_HIP_DELAY_DEPTH", 4)));
+                    // depth: a pivot's head grows with the pivots pending (the candidate row gets them all applied before it is
+                    // published), the sweep shrinks: measured best 8 at 65 rows per workgroup (16385 x 16385: 275 us per
+                    // pivot; 328 at 4), 6 at 17 (4097 x 16385: 106), 4 at 9 (2049 x 16385: 76)
+                    const int depth = std::min(8, std::max(2, env_int("YALPS_HIP_DELAY_DEPTH", (rows_per_block + 1) / 3)));
                     const size_t lds3 = sizeof(double) * (2 * 512 * 16 + (2 * (size_t)depth + 2) * (size_t)rows_per_block) +
                                         sizeof(int32_t) * (size_t)rows_per_block;
                     if (depth >= 2 && lds3 <= 150 * 1024) {
