@@ -861,6 +861,8 @@ SWEEP = [  # M, N, pivots, env, expected kernel, checkCycles
     (300, 9000, 60, {"YALPS_HIP_SWEEP_NT": "1", "YALPS_HIP_DELAY_MIN_ROWS": "1"}, "stream3_kernel<512,16,nt>", False),
     (2100, 12345, 51, {"YALPS_HIP_DELAY_DEPTH": "4"}, "stream3_kernel<512,16>", False),
     (2100, 12345, 7, {"YALPS_HIP_DELAY_DEPTH": "3"}, "stream3_kernel<512,16>", False),
+    (1400, 8000, 41, {"YALPS_HIP_DELAY_KERNEL": "3", "YALPS_HIP_DELAY_NT": "1"}, "stream3_kernel<512,8,nt>", False),
+    (4300, 4000, 33, {"YALPS_HIP_DELAY_KERNEL": "3"}, "stream3_kernel<512,4>", False),
     (1400, 8000, 80, {"YALPS_HIP_SWEEP": "2", "YALPS_HIP_DELAY": "0"}, "sweep_kernel<512,8>", False),
     (2500, 5000, 60, {"YALPS_HIP_SWEEP": "2", "YALPS_HIP_SWEEP_NT": "1", "YALPS_HIP_DELAY": "0"}, "sweep_kernel<512,8,nt>", False),
     (900, 7000, 60, {"YALPS_HIP_SWEEP": "2"}, "sweep_kernel<512,8>", True),

@@ -13,6 +13,12 @@ python3 tools/pmc_summary.py $out/pmc_write WRITE_SIZE > $out/write_summary.json
 python3 tools/resident_stages.py --size 2048 > $out/stages_2048.json 2> $out/stages.err
 YALPS_HIP_RESIDENT_GEN=1 python3 tools/resident_stages.py --size 2048 > $out/stages_2048_gen1.json 2>> $out/stages.err
 python3 tools/shape_sweep.py 32x32 128x128 256x256 512x512 1024x1024 1536x1536 2048x2048 2560x2560 3072x3072 3300x3000 4096x4096 5000x5000 512x4096 4096x512 1000x6000 10000x1000 11000x900 12000x1500 1024x8000 256x8192 8192x8192 1024x16384 1000x20000 > $out/shape_sweep.txt 2>&1
+# delayed row updates (stream2_kernel / stream3_kernel) against one sweep per pivot, same box, bounded launches
+: > $out/delay_table.txt
+for shape in "--size 16384 --pivots 240" "--size 16384 --rows 4096 --pivots 480" "--size 16384 --rows 2048 --pivots 600" "--size 16384 --rows 1024 --pivots 1500" "--size 8192 --pivots 800" "--size 6000 --pivots 1200" "--size 5000 --pivots 2000" "--size 4096 --pivots 2000" "--size 1500 --rows 12000 --pivots 2000"; do
+  for dl in 1 0; do YALPS_HIP_DELAY=$dl python3 tools/profile_solve.py $shape >> $out/delay_table.txt; done
+done
+python3 bench.py --size 16384 --steps 1 --warmup 0 --cpu-pivots 0 --sweep-launches 2 > $out/bench_16384.json 2> $out/bench_16384.err
 python3 bench_bnb.py > $out/bnb.json 2> $out/bnb.err
 python3 bench_table.py > $out/table.json 2> $out/table.err
 python3 bench.py --workload sharded --size 16384 --gpus 1 --steps 2 --warmup 1 2> $out/shard16384.err | grep "^{" > $out/shard16384.json

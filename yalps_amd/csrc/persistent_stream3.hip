@@ -20,6 +20,7 @@ namespace {
 #define S3VARIANT(T, J, NT) {T, J, NT, reinterpret_cast<const void *>(&stream3_kernel<T, J, NT != 0>)}
 } // namespace
 PersistentTable yalps_stream3_table() {
-    static const PersistentEntry kStream3[] = {S3VARIANT(512, 16, 0), S3VARIANT(512, 16, 1)};
+    static const PersistentEntry kStream3[] = {S3VARIANT(512, 16, 0), S3VARIANT(512, 16, 1), S3VARIANT(512, 8, 0), S3VARIANT(512, 8, 1),
+                                               S3VARIANT(512, 4, 0), S3VARIANT(512, 4, 1)};
     return {kStream3, (int)(sizeof kStream3 / sizeof kStream3[0])};
 }

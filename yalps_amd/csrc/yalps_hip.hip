@@ -679,7 +679,23 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
             const size_t fixed = sizeof(double) * 2 * (size_t)rows_per_block + sizeof(int32_t) * (size_t)rows_per_block;
             int depth = (int)std::min<size_t>(4, (150 * 1024 - fixed) / per_pivot);
             depth = std::min(depth, std::max(1, env_int("YALPS_HIP_DELAY_DEPTH", 4))); // (measured: 4 as good as 8, 5001 x 5001 10 % better than 2)
-            if (depth >= 2) {
+            // beyond the Infinity Cache stream3_kernel's placement (pending rows in L2, up to 8 of them) wins over LDS for two
+            // to four (8193 x 8193: 84 against 105 us per pivot); inside it, where HBM is not the limit, it loses (5001 x 5001:
+            // 46 against 35).  YALPS_HIP_DELAY_KERNEL=2 / 3 forces one.
+            // (8193 x 4097 and 6001 x 6001, 270-290 MB: still mostly out of the cache, stream2_kernel 43 / 50 against 45 / 56 us)
+            const int want_kernel = env_int("YALPS_HIP_DELAY_KERNEL", tab_bytes2 > ((size_t)384 << 20) ? 3 : 2);
+            if (want_kernel == 3 && T * J >= 2048) {
+                const int sJ = T * J / 512, depth3 = std::min(8, std::max(2, env_int("YALPS_HIP_DELAY_DEPTH", (rows_per_block + 1) / 3)));
+                const size_t lds3 = sizeof(double) * (2 * 512 * (size_t)sJ + (2 * (size_t)depth3 + 2) * (size_t)rows_per_block) + sizeof(int32_t) * (size_t)rows_per_block;
+                for (const RVariant &v : kStream3)
+                    if (v.T == 512 && v.J == sJ && v.R == want_nt2) t->svar2 = v;
+                if (t->svar2.fn) {
+                    t->sshmem2 = lds3;
+                    d.delay_depth = depth3;
+                    HIP_TRY(hipMalloc(&d.pend, sizeof(double) * (size_t)t->nb * depth3 * d.pitch));
+                    t->stream3 = true;
+                }
+            } else if (depth >= 2) {
                 for (int nt = want_nt2; nt >= 0 && !t->svar2.fn; nt--) // (the plain form where no non-temporal one is built)
                     for (const RVariant &v : kStream2)
                         if (v.T * v.J == T * J && v.R == nt) t->svar2 = v; // (same row span; its own lane count)
