@@ -9,10 +9,10 @@
 // columns (BASELINE config 5), where neither a lane's 16 units of the objective replica nor two normalised pivot rows of
 // 131 KB fit where stream2_kernel keeps them.  Placement:
 //   * the objective replica lives in LDS (2 T J doubles: every lane reads and writes the columns it also holds of a row);
-//   * the pending normalised pivot rows live in a per-workgroup scratch in global memory (d.pend: [workgroup][depth][pitch],
-//     262-524 KB per workgroup: L2-resident): written when the pivot is decided (plain stores, by the lane that will read
-//     them during the sweep), read 16 bytes per lane, unit and pending pivot during the sweep (L2 traffic as large as the
-//     rows' HBM traffic per pending pivot, which L2 has to spare), single entries for the scalar chains with sc1 loads;
+//   * the pending normalised pivot rows live in a scratch in global memory shared by all workgroups (d.pend: [2 sets][depth]
+//     [pitch], <= 2 MB: resident in every XCD's L2): written when the pivot is decided (plain stores, by the lane that will
+//     read them during the sweep; every workgroup stores the same bytes), read 16 bytes per lane, unit and pending pivot per
+//     two rows during the sweep, single entries for the scalar chains with agent-scope loads;
 //   * a pivot row passes through registers 8 units per lane at a time (normalise, objective replica, pricing in one pass).
 // ------------------------------------------------------------------------------------------
 template <int T, int J, bool NT>
@@ -53,7 +53,13 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
            *rhsv = lav + rpw; // (nqv: what replaces a row's pivot-column entry, :25 / :36 -- one division per row and pivot, by one lane)
     int *tlist = reinterpret_cast<int *>(rhsv + rpw);
     const double flushed = __longlong_as_double((long long)FLUSHED);
-    double *prow0 = d.pend + (size_t)b * depth * pitch; // my scratch: the pending normalised pivot rows
+    // The pending normalised pivot rows: ONE scratch for all workgroups -- every workgroup computes the same rows from the same
+    // published bytes and stores them to the same place (identical values; a lane only ever reads back columns it stores
+    // itself, or, for the scalar chains, columns stored before its workgroup's barrier).  Private copies (256 x depth x 131 KB)
+    // did not stay in the L2s and were re-read from the Infinity Cache / HBM with every row.  Two sets, taken in turns from
+    // sweep to sweep: a workgroup that is through with its sweep may store the next pivot's row while another still sweeps
+    // (it cannot get further: deciding the pivot after that needs every workgroup's next candidate, published after its sweep).
+    double *prow0 = d.pend;
 
     // (rows and scratch rows are addressed through a buffer descriptor of ONE row + a 32-bit lane offset, like sweep_kernel:
     // flat addressing held a 64-bit pair per unit, pivot and row in flight -- 192 spilled registers)
@@ -79,7 +85,7 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
     __syncthreads();
 
     // ---- the pending pivots (npend of them, [0] the oldest): scalars, pivot rows and my rows' pivot-column entries in LDS ----
-    int npend = 0;
+    int npend = 0, pset = 0; // (pset: which of the two scratch sets holds the rows pending now)
     // entry (my row slot i, mat column c) after ONE pending pivot, given the entry before it (:14-25, :31-36 for one element)
     auto after1 = [&](double p, const double *colvp, const double *nqvp, int lslotp, int colxp, int i, double v, int c)
                       __attribute__((always_inline)) {
@@ -219,6 +225,8 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
             }
         }
         npend = 0;
+        pset ^= 1;
+        prow0 = d.pend + (size_t)pset * depth * pitch;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads(); // my rows are complete in memory (and the LDS arrays free) before anything reads them again
     };

@@ -692,7 +692,7 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
                 if (t->svar2.fn) {
                     t->sshmem2 = lds3;
                     d.delay_depth = depth3;
-                    HIP_TRY(hipMalloc(&d.pend, sizeof(double) * (size_t)t->nb * depth3 * d.pitch));
+                    HIP_TRY(hipMalloc(&d.pend, sizeof(double) * 2 * (size_t)depth3 * d.pitch));
                     t->stream3 = true;
                 }
             } else if (depth >= 2) {
@@ -742,7 +742,7 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
                         if (t->svar2.fn) {
                             t->sshmem2 = lds3;
                             d.delay_depth = depth;
-                            HIP_TRY(hipMalloc(&d.pend, sizeof(double) * (size_t)t->nb * depth * d.pitch));
+                            HIP_TRY(hipMalloc(&d.pend, sizeof(double) * 2 * (size_t)depth * d.pitch)); // (two sets of `depth` rows, shared by all workgroups)
                             t->stream3 = true;
                         }
                     }
