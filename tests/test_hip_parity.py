@@ -465,15 +465,18 @@ def test_resident_lds_rows_whole_solves(nat, ctx, oracle, monkeypatch, variant, 
 
 
 # ---- persistent in-place kernels (stream2_kernel: two pivots per sweep; stream_kernel) for tableaux beyond the on-chip size ----
-@pytest.mark.parametrize("delay", ["1", "0"], ids=["stream2", "stream"])
+@pytest.mark.parametrize("delay", ["3", "2", "0"], ids=["delayed", "stream2", "stream"])
 @pytest.mark.parametrize("M,N,pivots", [(2800, 3300, 120), (1400, 8000, 81), (12000, 1500, 60), (11000, 900, 61), (12000, 400, 60),
-                                        (2800, 3300, 1), (1400, 8000, 2), (2800, 3300, 3)])
+                                        (2800, 3300, 1), (1400, 8000, 2), (2800, 3300, 3), (4400, 5000, 37)])
 def test_inplace_path_matches_restatement(nat, ctx, monkeypatch, M, N, pivots, delay):
-    """Dense tableaux that do not fit the register-resident kernel: `pivots` pivots (phase 1 first) through stream2_kernel
-    (the rows get two pivots' eliminations per sweep; odd budgets leave through the one-pivot flush) and through
-    stream_kernel, against the pinned numpy restatement, bit for bit."""
+    """Dense tableaux that do not fit the register-resident kernel: `pivots` pivots (phase 1 first) through the kernels with
+    delayed row updates (the rows get several pivots' eliminations per sweep; budgets that are no multiple of the depth
+    leave through a shorter flush) -- the default choice (stream3_kernel for rows of more than 2048 columns, stream2_kernel
+    below), stream2_kernel wherever it applies -- and through stream_kernel, against the pinned numpy restatement, bit for bit."""
     from tests import _np_simplex as NP
-    monkeypatch.setenv("YALPS_HIP_DELAY", delay)
+    monkeypatch.setenv("YALPS_HIP_DELAY", "0" if delay == "0" else "1")
+    if delay == "2":
+        monkeypatch.setenv("YALPS_HIP_DELAY_KERNEL", delay)
     monkeypatch.setenv("YALPS_HIP_SWEEP", "0")  # (the 8001-column shape: stream_kernel<1024,4>, not sweep_kernel)
     monkeypatch.setenv("YALPS_HIP_LDS_ROWS", "0")  # (two of the shapes would fit with rows parked in LDS)
     w, h = N + 1, M + 1
@@ -491,7 +494,8 @@ def test_inplace_path_matches_restatement(nat, ctx, monkeypatch, M, N, pivots, d
         got, gpos, gvar = t.download()
     finally:
         t.close()
-    assert info["last_path"] == "inplace" and info["inplace"].startswith("stream2_kernel" if delay == "1" else "stream_kernel"), info
+    want = "stream_kernel" if delay == "0" else "stream2_kernel" if delay == "2" or N <= 2048 else "stream3_kernel"
+    assert info["last_path"] == "inplace" and info["inplace"].startswith(want), info
     assert (status, npiv) == (est, epiv) and G.same_number(result, eres)
     assert np.array_equal(gpos, rpos) and np.array_equal(gvar, rvar)
     assert np.array_equal(got.view(np.int64), ref.view(np.int64))
@@ -608,7 +612,7 @@ def test_two_tableaux_share_a_kernel_with_different_lds_needs(nat, ctx):
             t, m, w, h, pos = tabs[k]
             t.upload(m, h, pos, pos.copy())
             st, res, piv, _ = t.solve(max_pivots=20)
-            assert t.info()["last_path"] == "inplace" and t.info()["inplace"] == "stream2_kernel<512,8>", t.info()
+            assert t.info()["last_path"] == "inplace" and t.info()["inplace"] == "stream2_kernel<512,8>", t.info()  # (two rows per workgroup: the LDS form)
             runs.append((k, st, res, piv, t.download()))
     finally:
         for t, *_ in tabs:
@@ -858,18 +862,19 @@ SWEEP = [  # M, N, pivots, env, expected kernel, checkCycles
     (2100, 12345, 50, {"YALPS_HIP_DELAY": "0"}, "sweep_kernel<512,16>", False),
     # stream3_kernel (delayed updates for 8194 .. 16385 columns: objective replica in LDS, pending rows in a global scratch)
     (600, 16000, 71, {"YALPS_HIP_DELAY_MIN_ROWS": "1"}, "stream3_kernel<512,16>", False),
-    (300, 9000, 60, {"YALPS_HIP_SWEEP_NT": "1", "YALPS_HIP_DELAY_MIN_ROWS": "1"}, "stream3_kernel<512,16,nt>", False),
+    (300, 9000, 60, {"YALPS_HIP_DELAY_NT": "1", "YALPS_HIP_DELAY_MIN_ROWS": "1"}, "stream3_kernel<512,16,nt>", False),
     (2100, 12345, 51, {"YALPS_HIP_DELAY_DEPTH": "4"}, "stream3_kernel<512,16>", False),
     (2100, 12345, 7, {"YALPS_HIP_DELAY_DEPTH": "3"}, "stream3_kernel<512,16>", False),
-    (1400, 8000, 41, {"YALPS_HIP_DELAY_KERNEL": "3", "YALPS_HIP_DELAY_NT": "1"}, "stream3_kernel<512,8,nt>", False),
-    (4300, 4000, 33, {"YALPS_HIP_DELAY_KERNEL": "3"}, "stream3_kernel<512,4>", False),
+    (1400, 8000, 41, {"YALPS_HIP_DELAY_NT": "1"}, "stream3_kernel<512,8,nt>", False),
+    (4300, 4000, 33, {}, "stream3_kernel<512,4>", False),
+    (4400, 5500, 29, {"YALPS_HIP_DELAY_DEPTH": "5"}, "stream3_kernel<512,6>", False),
     (1400, 8000, 80, {"YALPS_HIP_SWEEP": "2", "YALPS_HIP_DELAY": "0"}, "sweep_kernel<512,8>", False),
     (2500, 5000, 60, {"YALPS_HIP_SWEEP": "2", "YALPS_HIP_SWEEP_NT": "1", "YALPS_HIP_DELAY": "0"}, "sweep_kernel<512,8,nt>", False),
     (900, 7000, 60, {"YALPS_HIP_SWEEP": "2"}, "sweep_kernel<512,8>", True),
     # stream2_kernel (two pivots per sweep) with the same awkward data; its non-temporal forms; odd budgets
-    (1400, 8000, 81, {"YALPS_HIP_DELAY_NT": "1"}, "stream2_kernel<512,8,nt>", False),
-    (4300, 4000, 61, {"YALPS_HIP_DELAY_NT": "1"}, "stream2_kernel<1024,2,nt>", False),
-    (900, 7000, 60, {}, "stream2_kernel<512,8>", False),
+    (1400, 8000, 81, {"YALPS_HIP_DELAY_NT": "1", "YALPS_HIP_DELAY_KERNEL": "2"}, "stream2_kernel<512,8,nt>", False),
+    (4300, 4000, 61, {"YALPS_HIP_DELAY_NT": "1", "YALPS_HIP_DELAY_KERNEL": "2"}, "stream2_kernel<1024,2,nt>", False),
+    (900, 7000, 60, {"YALPS_HIP_DELAY_KERNEL": "2"}, "stream2_kernel<512,8>", False),
 ]
 
 

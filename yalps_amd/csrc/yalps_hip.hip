@@ -668,41 +668,6 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
             if (v.T == T && v.J == J) t->svar_check = v;
         t->sshmem = sizeof(double) * ((size_t)d.pitch + 3 * (size_t)rows_per_block) + sizeof(int32_t) * (size_t)rows_per_block;
         if (t->sshmem > 150 * 1024) t->svar.fn = t->svar_check.fn = nullptr;
-        // two pivots per sweep where stream_kernel's lanes x units span the row and two pivot rows fit in LDS
-        if (t->svar.fn && env_int("YALPS_HIP_DELAY", 1)) {
-            const size_t tab_bytes2 = sizeof(double) * (size_t)d.pitch * hcap;
-            int want_nt2 = tab_bytes2 > SWEEP_BEYOND_CACHE ? 1 : 0;
-            if (const char *e = std::getenv("YALPS_HIP_DELAY_NT")) want_nt2 = std::atoi(e) != 0;
-            // as many pending pivots as LDS holds normalised pivot rows (+ two scalars per row of mine) for, at most 4:
-            // the rows then cost 16 / depth bytes of traffic per element and pivot (YALPS_HIP_DELAY_DEPTH caps it)
-            const size_t per_pivot = sizeof(double) * ((size_t)d.pitch + 2 * (size_t)rows_per_block);
-            const size_t fixed = sizeof(double) * 2 * (size_t)rows_per_block + sizeof(int32_t) * (size_t)rows_per_block;
-            int depth = (int)std::min<size_t>(4, (150 * 1024 - fixed) / per_pivot);
-            depth = std::min(depth, std::max(1, env_int("YALPS_HIP_DELAY_DEPTH", 4))); // (measured: 4 as good as 8, 5001 x 5001 10 % better than 2)
-            // beyond the Infinity Cache stream3_kernel's placement (pending rows in L2, up to 8 of them) wins over LDS for two
-            // to four (8193 x 8193: 84 against 105 us per pivot); inside it, where HBM is not the limit, it loses (5001 x 5001:
-            // 46 against 35).  YALPS_HIP_DELAY_KERNEL=2 / 3 forces one.
-            // (8193 x 4097 and 6001 x 6001, 270-290 MB: still mostly out of the cache, stream2_kernel 43 / 50 against 45 / 56 us)
-            const int want_kernel = env_int("YALPS_HIP_DELAY_KERNEL", tab_bytes2 > ((size_t)384 << 20) ? 3 : 2);
-            if (want_kernel == 3 && T * J >= 2048) {
-                const int sJ = T * J / 512, depth3 = std::min(8, std::max(2, env_int("YALPS_HIP_DELAY_DEPTH", (rows_per_block + 1) / 3)));
-                const size_t lds3 = sizeof(double) * (2 * 512 * (size_t)sJ + (2 * (size_t)depth3 + 2) * (size_t)rows_per_block) + sizeof(int32_t) * (size_t)rows_per_block;
-                for (const RVariant &v : kStream3)
-                    if (v.T == 512 && v.J == sJ && v.R == want_nt2) t->svar2 = v;
-                if (t->svar2.fn) {
-                    t->sshmem2 = lds3;
-                    d.delay_depth = depth3;
-                    HIP_TRY(hipMalloc(&d.pend, sizeof(double) * 2 * (size_t)depth3 * d.pitch));
-                    t->stream3 = true;
-                }
-            } else if (depth >= 2) {
-                for (int nt = want_nt2; nt >= 0 && !t->svar2.fn; nt--) // (the plain form where no non-temporal one is built)
-                    for (const RVariant &v : kStream2)
-                        if (v.T * v.J == T * J && v.R == nt) t->svar2 = v; // (same row span; its own lane count)
-                t->sshmem2 = fixed + (size_t)depth * per_pivot;
-                d.delay_depth = depth;
-            }
-        }
         // what streams from HBM anyway goes to sweep_kernel: rows of 8194 .. 16385 columns (no stream_kernel spans them), and
         // 4098 .. 8193-column tableaux too big for the Infinity Cache (measured at 8193 x 8193: stream_kernel 5.1 TB/s)
         const size_t tab_bytes = sizeof(double) * (size_t)d.pitch * hcap;
@@ -725,28 +690,50 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
                     t->sshmem = lds;
                     d.sw_nt = want_nt;
                 }
-                // rows of 8194 .. 16385 columns with delayed updates: stream3_kernel (objective replica in LDS, the pending
-                // pivot rows in a per-workgroup scratch in global memory), as many pivots per sweep as YALPS_HIP_DELAY_DEPTH says
-                // (measured: 16385 x 16385 738 -> 480 us per pivot at depth 4, 4097 x 16385 189 -> 148; with few rows per
-                // workgroup the longer head of its pivots loses: 1025 x 16385 50 -> 64 us, those stay with sweep_kernel)
-                if (t->sweep && J == 8 && env_int("YALPS_HIP_DELAY", 1) && rows_per_block >= env_int("YALPS_HIP_DELAY_MIN_ROWS", 8)) {
-                    // depth: a pivot's head grows with the pivots pending (the candidate row gets them all applied before it is
-                    // published), the sweep shrinks: measured best 8 at 65 rows per workgroup (16385 x 16385: 275 us per
-                    // pivot; 328 at 4), 6 at 17 (4097 x 16385: 106), 4 at 9 (2049 x 16385: 76)
-                    const int depth = std::min(8, std::max(2, env_int("YALPS_HIP_DELAY_DEPTH", (rows_per_block + 1) / 3)));
-                    const size_t lds3 = sizeof(double) * (2 * 512 * 16 + (2 * (size_t)depth + 2) * (size_t)rows_per_block) +
-                                        sizeof(int32_t) * (size_t)rows_per_block;
-                    if (depth >= 2 && lds3 <= 150 * 1024) {
-                        for (const RVariant &v : kStream3)
-                            if (v.T == 512 && v.J == 16 && v.R == want_nt) t->svar2 = v;
-                        if (t->svar2.fn) {
-                            t->sshmem2 = lds3;
-                            d.delay_depth = depth;
-                            HIP_TRY(hipMalloc(&d.pend, sizeof(double) * 2 * (size_t)depth * d.pitch)); // (two sets of `depth` rows, shared by all workgroups)
-                            t->stream3 = true;
-                        }
-                    }
-                }
+            }
+        }
+    }
+    // Delayed row updates: where an in-place kernel applies (and no checkCycles), several pivots per sweep.
+    //   stream3_kernel<512, J> (objective replica in LDS, the pending pivot rows in a global scratch shared by all workgroups,
+    //   up to 8 of them): rows of 2049 .. 16385 columns with at least 4 rows per workgroup;
+    //   stream2_kernel (pending rows in LDS, up to 4): narrower rows, and where YALPS_HIP_DELAY_KERNEL=2 asks for it.
+    // Measured against each other on one box: stream3 24.0 / 44.7 / 33.4 / 57.6 / 190 us per pivot at 4097^2 / 6001^2 /
+    // 8193 x 4097 / 8193^2 / 16385^2, stream2 26.2 / 50.0 / 42.8 / 105 / --; 1025 x 16385: stream3 43.6, sweep_kernel 50.3.
+    if (t->svar.fn && env_int("YALPS_HIP_DELAY", 1)) {
+        const int units = d.pitch / 2;
+        const size_t tab_bytes2 = sizeof(double) * (size_t)d.pitch * hcap;
+        int want_nt2 = tab_bytes2 > SWEEP_BEYOND_CACHE ? 1 : 0;
+        if (const char *e = std::getenv("YALPS_HIP_DELAY_NT")) want_nt2 = std::atoi(e) != 0;
+        int sJ = 0;
+        for (int cand : {4, 6, 8, 16})
+            if (!sJ && 512 * cand >= units) sJ = cand;
+        const int want_kernel = env_int("YALPS_HIP_DELAY_KERNEL", units > 1024 ? 3 : 2);
+        if (want_kernel == 3 && sJ && units > 512 && rows_per_block >= env_int("YALPS_HIP_DELAY_MIN_ROWS", 4)) {
+            // depth: a pivot's head grows with the pivots pending (the candidate row gets them all applied before it is
+            // published), the sweep shrinks: measured best 8 at 65 and 33 rows per workgroup, 6-8 at 17, 4 at 5-9
+            const int depth3 = std::min(8, std::max(2, env_int("YALPS_HIP_DELAY_DEPTH", std::max(4, (rows_per_block + 1) / 3))));
+            const size_t lds3 = sizeof(double) * (2 * 512 * (size_t)sJ + (2 * (size_t)depth3 + 2) * (size_t)rows_per_block) + sizeof(int32_t) * (size_t)rows_per_block;
+            if (lds3 <= 150 * 1024)
+                for (const RVariant &v : kStream3)
+                    if (v.T == 512 && v.J == sJ && v.R == want_nt2) t->svar2 = v;
+            if (t->svar2.fn) {
+                t->sshmem2 = lds3;
+                d.delay_depth = depth3;
+                HIP_TRY(hipMalloc(&d.pend, sizeof(double) * 2 * (size_t)depth3 * d.pitch)); // (two sets of `depth` rows, shared by all workgroups)
+                t->stream3 = true;
+            }
+        }
+        if (!t->svar2.fn && T * J <= 4096) { // stream2_kernel: as many pending pivots as LDS holds pivot rows (+ two scalars per row of mine) for, at most 4
+            const size_t per_pivot = sizeof(double) * ((size_t)d.pitch + 2 * (size_t)rows_per_block);
+            const size_t fixed = sizeof(double) * 2 * (size_t)rows_per_block + sizeof(int32_t) * (size_t)rows_per_block;
+            int depth = (int)std::min<size_t>(4, (150 * 1024 - fixed) / per_pivot);
+            depth = std::min(depth, std::max(1, env_int("YALPS_HIP_DELAY_DEPTH", 4)));
+            if (depth >= 2) {
+                for (int nt = want_nt2; nt >= 0 && !t->svar2.fn; nt--) // (the plain form where no non-temporal one is built)
+                    for (const RVariant &v : kStream2)
+                        if (v.T * v.J == T * J && v.R == nt) t->svar2 = v; // (same row span; its own lane count)
+                t->sshmem2 = fixed + (size_t)depth * per_pivot;
+                d.delay_depth = depth;
             }
         }
     }
