@@ -19,6 +19,8 @@ for shape in "--size 16384 --pivots 240" "--size 16384 --rows 4096 --pivots 480"
   for dl in 1 0; do YALPS_HIP_DELAY=$dl python3 tools/profile_solve.py $shape >> $out/delay_table.txt; done
 done
 python3 bench.py --size 16384 --steps 1 --warmup 0 --cpu-pivots 0 --sweep-launches 2 > $out/bench_16384.json 2> $out/bench_16384.err
+python3 tools/netlib_paths.py > $out/netlib_paths.txt 2>&1
+YALPS_HIP_DELAY=0 python3 tools/netlib_paths.py > $out/netlib_paths_nodelay.txt 2>&1
 python3 bench_bnb.py > $out/bnb.json 2> $out/bnb.err
 python3 bench_table.py > $out/table.json 2> $out/table.err
 python3 bench.py --workload sharded --size 16384 --gpus 1 --steps 2 --warmup 1 2> $out/shard16384.err | grep "^{" > $out/shard16384.json
@@ -37,7 +39,7 @@ for shape in "16384 0 300" "8192 0 800" "16384 1024 2000" "16384 4096 600"; do
   find $out/sw_$tag -name "*kernel_stats.csv" -exec cp {} $out/sweep_${tag}_kernel_stats.csv \; ; rm -rf $out/sw_$tag
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c -d $out/swpmc --output-format csv -- python3 tools/profile_solve.py --size $1 $rows --pivots $3 > /dev/null 2>&1
-    python3 tools/pmc_summary.py $out/swpmc $c sweep_kernel > $out/sweep_${tag}_$c.json; rm -rf $out/swpmc
+    python3 tools/pmc_summary.py $out/swpmc $c _kernel > $out/sweep_${tag}_$c.json; rm -rf $out/swpmc
   done
 done
 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 2 --steps 3 --warmup 1 2> $out/rehearsal_replicas2.err | grep "^{" > $out/rehearsal_replicas2.json
