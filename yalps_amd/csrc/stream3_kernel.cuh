@@ -25,7 +25,7 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
     __shared__ int sh_pl[MAXD], sh_pc[MAXD]; // the pending pivots, oldest first: my slot of the pivot row (-1: not mine), pivot column (mat index)
     __shared__ int sh_fast[MAXD][T / 64];       // per wave: nothing of its slice of that pivot row was flushed (:31 select-free path)
     constexpr int JC = J > 8 ? 8 : J; // units per lane that pass through registers at a time (a pivot row being decided)
-    constexpr int JA = J > 2 ? 2 : J; // ... of a pending pivot row while it is applied to the rows in flight
+    constexpr int JA = J > 8 ? 8 : J; // ... of a pending pivot row while it is applied to the rows in flight
     extern __shared__ __attribute__((aligned(16))) double sm_dyn[]; // olds[2 T J] (objective replica), colv[depth][rpw], nqv[depth][rpw], lav[rpw], rhsv[rpw], tlist[rpw] (int)
 
     const int tid = threadIdx.x, NB = d.nb, b = blockIdx.x;
