@@ -121,7 +121,7 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
         __syncthreads();
     };
     // the pending pivots applied to (up to) RB half-rows held in registers: units [u0, u0 + JH) of my row slots ri[0 .. cnt)
-    constexpr int JH = J > 8 ? 8 : J, RB = 2;
+    constexpr int JH = J > 8 ? 8 : J, RB = J > 8 ? 2 : 3;
     auto apply_batch = [&](int u0, double2 (&xb)[RB][JH], const int (&ri)[RB], int cnt) __attribute__((always_inline)) {
 #pragma unroll 1
         for (int p = 0; p < npend; p++) { // (a run-time loop: its scalars are read once per batch of RB half-rows)
