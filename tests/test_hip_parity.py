@@ -471,8 +471,7 @@ def test_resident_lds_rows_whole_solves(nat, ctx, oracle, monkeypatch, variant, 
 def test_inplace_path_matches_restatement(nat, ctx, monkeypatch, M, N, pivots, delay):
     """Dense tableaux that do not fit the register-resident kernel: `pivots` pivots (phase 1 first) through the kernels with
     delayed row updates (the rows get several pivots' eliminations per sweep; budgets that are no multiple of the depth
-    leave through a shorter flush) -- the default choice (stream3_kernel for rows of more than 2048 columns, stream2_kernel
-    below), stream2_kernel wherever it applies -- and through stream_kernel, against the pinned numpy restatement, bit for bit."""
+    leave through a shorter flush) -- the default choice (stream3_kernel), stream2_kernel wherever it applies -- and through stream_kernel, against the pinned numpy restatement, bit for bit."""
     from tests import _np_simplex as NP
     monkeypatch.setenv("YALPS_HIP_DELAY", "0" if delay == "0" else "1")
     if delay == "2":
@@ -494,7 +493,7 @@ def test_inplace_path_matches_restatement(nat, ctx, monkeypatch, M, N, pivots, d
         got, gpos, gvar = t.download()
     finally:
         t.close()
-    want = "stream_kernel" if delay == "0" else "stream2_kernel" if delay == "2" or N <= 2048 else "stream3_kernel"
+    want = "stream_kernel" if delay == "0" else "stream2_kernel" if delay == "2" else "stream3_kernel"
     assert info["last_path"] == "inplace" and info["inplace"].startswith(want), info
     assert (status, npiv) == (est, epiv) and G.same_number(result, eres)
     assert np.array_equal(gpos, rpos) and np.array_equal(gvar, rvar)
@@ -653,17 +652,18 @@ def test_inplace_fallback_restores_the_tableau(oracle, lds_rows, path):
 TALL = [("inplace", "0"), ("resident", "1")]  # 11001 rows: stream_kernel, or resident_kernel<512,1,38> + 5 rows per workgroup in LDS
 
 
-@pytest.mark.parametrize("path,lds_rows,delay", [("inplace", "0", "1"), ("inplace", "0", "0"), ("resident", "1", "1")],
-                         ids=["stream2", "stream", "resident-lds"])
+@pytest.mark.parametrize("path,lds_rows,delay", [("inplace", "0", "3"), ("inplace", "0", "2"), ("inplace", "0", "0"), ("resident", "1", "3")],
+                         ids=["stream3", "stream2", "stream", "resident-lds"])
 @pytest.mark.parametrize("kind", ["unbounded", "infeasible", "optimal", "optimal-degenerate"])
 def test_inplace_path_terminal_statuses(nat, ctx, monkeypatch, kind, path, lds_rows, delay):
     """The persistent kernels' exits other than the pivot budget, on a tall narrow LP (11001 x 61: beyond the register
-    variants) solved to the end through stream2_kernel (which may leave with a pivot still pending: the flush), through
-    stream_kernel and through the resident kernel with LDS rows: unbounded after 124 pivots (result = the column),
+    variants) solved to the end through stream3_kernel and stream2_kernel (which may leave with pivots still pending: the
+    flush), through stream_kernel and through the resident kernel with LDS rows: unbounded after 124 pivots (result = the column),
     infeasible after 41 phase-1 pivots, optimal, and optimal with every 10th right-hand side zero (ties, ratios <= precision)."""
     from tests import _np_simplex as NP
     monkeypatch.setenv("YALPS_HIP_LDS_ROWS", lds_rows)
-    monkeypatch.setenv("YALPS_HIP_DELAY", delay)
+    monkeypatch.setenv("YALPS_HIP_DELAY", "0" if delay == "0" else "1")
+    monkeypatch.setenv("YALPS_HIP_DELAY_KERNEL", "2" if delay == "2" else "3")
     M, N = 11000, 60
     w, h = N + 1, M + 1
     m = nat.dense_lp(M, N, 21)

@@ -21,6 +21,7 @@ namespace {
 } // namespace
 PersistentTable yalps_stream3_table() {
     static const PersistentEntry kStream3[] = {S3VARIANT(512, 16, 0), S3VARIANT(512, 16, 1), S3VARIANT(512, 8, 0), S3VARIANT(512, 8, 1),
-                                               S3VARIANT(512, 6, 0), S3VARIANT(512, 6, 1), S3VARIANT(512, 4, 0), S3VARIANT(512, 4, 1)};
+                                               S3VARIANT(512, 6, 0), S3VARIANT(512, 6, 1), S3VARIANT(512, 4, 0), S3VARIANT(512, 4, 1),
+                                               S3VARIANT(512, 2, 0), S3VARIANT(512, 2, 1), S3VARIANT(512, 1, 0), S3VARIANT(512, 1, 1)};
     return {kStream3, (int)(sizeof kStream3 / sizeof kStream3[0])};
 }

@@ -695,20 +695,21 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
     }
     // Delayed row updates: where an in-place kernel applies (and no checkCycles), several pivots per sweep.
     //   stream3_kernel<512, J> (objective replica in LDS, the pending pivot rows in a global scratch shared by all workgroups,
-    //   up to 8 of them): rows of 2049 .. 16385 columns with at least 4 rows per workgroup;
-    //   stream2_kernel (pending rows in LDS, up to 4): narrower rows, and where YALPS_HIP_DELAY_KERNEL=2 asks for it.
-    // Measured against each other on one box: stream3 24.0 / 44.7 / 33.4 / 57.6 / 190 us per pivot at 4097^2 / 6001^2 /
-    // 8193 x 4097 / 8193^2 / 16385^2, stream2 26.2 / 50.0 / 42.8 / 105 / --; 1025 x 16385: stream3 43.6, sweep_kernel 50.3.
+    //   up to 8 of them): rows of up to 16385 columns with at least 4 rows per workgroup;
+    //   stream2_kernel (pending rows in LDS, up to 4): fewer rows per workgroup, and where YALPS_HIP_DELAY_KERNEL=2 asks for it.
+    // Measured against each other on one box, us per pivot, stream3 / stream2: 4097^2 20.2 / 26.2, 6001^2 33.6 / 50.0,
+    // 8193 x 4097 30.0 / 42.8, 8193^2 48.3 / 105, 12001 x 1501 21.8 / 26.4, 11001 x 901 17.2 / 24.0, 16385^2 159 / --;
+    // 1025 x 16385: stream3 34.3, sweep_kernel 50.3.
     if (t->svar.fn && env_int("YALPS_HIP_DELAY", 1)) {
         const int units = d.pitch / 2;
         const size_t tab_bytes2 = sizeof(double) * (size_t)d.pitch * hcap;
         int want_nt2 = tab_bytes2 > SWEEP_BEYOND_CACHE ? 1 : 0;
         if (const char *e = std::getenv("YALPS_HIP_DELAY_NT")) want_nt2 = std::atoi(e) != 0;
         int sJ = 0;
-        for (int cand : {4, 6, 8, 16})
+        for (int cand : {1, 2, 4, 6, 8, 16})
             if (!sJ && 512 * cand >= units) sJ = cand;
-        const int want_kernel = env_int("YALPS_HIP_DELAY_KERNEL", units > 1024 ? 3 : 2);
-        if (want_kernel == 3 && sJ && units > 512 && rows_per_block >= env_int("YALPS_HIP_DELAY_MIN_ROWS", 4)) {
+        const int want_kernel = env_int("YALPS_HIP_DELAY_KERNEL", 3);
+        if (want_kernel == 3 && sJ && rows_per_block >= env_int("YALPS_HIP_DELAY_MIN_ROWS", 4)) {
             // depth: a pivot's head grows with the pivots pending (the candidate row gets them all applied before it is
             // published), the sweep shrinks: measured best 8 at 65 and 33 rows per workgroup, 6-8 at 17, 4 at 5-9
             const int depth3 = std::min(8, std::max(2, env_int("YALPS_HIP_DELAY_DEPTH", std::max(4, (rows_per_block + 1) / 3))));
