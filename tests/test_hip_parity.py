@@ -611,7 +611,7 @@ def test_two_tableaux_share_a_kernel_with_different_lds_needs(nat, ctx):
             t, m, w, h, pos = tabs[k]
             t.upload(m, h, pos, pos.copy())
             st, res, piv, _ = t.solve(max_pivots=20)
-            assert t.info()["last_path"] == "inplace" and t.info()["inplace"] == "stream2_kernel<512,8>", t.info()  # (two rows per workgroup: the LDS form)
+            assert t.info()["last_path"] == "inplace" and t.info()["inplace"] == "stream_kernel<1024,4>", t.info()  # (two rows per workgroup: one sweep per pivot)
             runs.append((k, st, res, piv, t.download()))
     finally:
         for t, *_ in tabs:

@@ -724,7 +724,8 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
                 t->stream3 = true;
             }
         }
-        if (!t->svar2.fn && T * J <= 4096) { // stream2_kernel: as many pending pivots as LDS holds pivot rows (+ two scalars per row of mine) for, at most 4
+        // (with two or three rows per workgroup there is nothing to save: 257 x 8193 16.6 us delayed against 14.5)
+        if (!t->svar2.fn && T * J <= 4096 && rows_per_block >= env_int("YALPS_HIP_DELAY_MIN_ROWS", 4)) { // stream2_kernel: as many pending pivots as LDS holds pivot rows (+ two scalars per row of mine) for, at most 4
             const size_t per_pivot = sizeof(double) * ((size_t)d.pitch + 2 * (size_t)rows_per_block);
             const size_t fixed = sizeof(double) * 2 * (size_t)rows_per_block + sizeof(int32_t) * (size_t)rows_per_block;
             int depth = (int)std::min<size_t>(4, (150 * 1024 - fixed) / per_pivot);
