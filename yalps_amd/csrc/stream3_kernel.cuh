@@ -481,7 +481,12 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
                     }
                 }
                 *reinterpret_cast<double2 *>(olds + c0) = ov;
-                row_st16<AUX_PLAIN>(rsrc_new, lane_off + 16 * T * (jb + j), 0, pn);
+                // (write-through: the scratch is written by workgroups of all eight XCDs, whose L2s are not coherent with each other.
+                // With write-back stores a dirty copy of this address from an earlier sweep generation could linger in another
+                // XCD's L2 and be written back OVER the fresh row after this XCD had evicted it: re-read, the row was stale in
+                // some 128-byte lines -- found by tools/soak_delay.py on a 2 % dense tableau after 1147 cases, one workgroup's
+                // three touched rows wrong in the pivot row's 54 non-zero columns, not reproducible run to run)
+                row_st16<AUX_SC1>(rsrc_new, lane_off + 16 * T * (jb + j), 0, pn);
             }
         }
         {
