@@ -86,7 +86,7 @@ struct Desc {
     int32_t sw_nt;
     // stream2_kernel: pivots whose eliminations are delayed and carried out together (as many pivot rows as LDS holds, <= 8)
     int32_t delay_depth;
-    double *pend; // stream3_kernel: [2 sets][delay_depth][pitch] the pending normalised pivot rows (one scratch for all workgroups)
+    double *pend; // stream3_kernel: [8 XCDs][2 sets][delay_depth][pitch] the pending normalised pivot rows (one scratch per XCD)
     // row shards swept IN PLACE (wide_kernel<.., true, ..>): the objective row is the one row every workgroup reads while
     // its owner rewrites it, so it alone stays ping-ponged, as two replicas [pitch] beside the tableau
     double *obj[2];

@@ -9,8 +9,8 @@
 // columns (BASELINE config 5), where neither a lane's 16 units of the objective replica nor two normalised pivot rows of
 // 131 KB fit where stream2_kernel keeps them.  Placement:
 //   * the objective replica lives in LDS (2 T J doubles: every lane reads and writes the columns it also holds of a row);
-//   * the pending normalised pivot rows live in a scratch in global memory shared by all workgroups (d.pend: [2 sets][depth]
-//     [pitch], <= 2 MB: resident in every XCD's L2): written when the pivot is decided (plain stores, by the lane that will
+//   * the pending normalised pivot rows live in a scratch in global memory shared by the workgroups of an XCD (d.pend: [8 XCDs]
+//     [2 sets][depth][pitch], <= 2 MB per XCD: resident in its L2): written when the pivot is decided (plain stores, by the lane that will
 //     read them during the sweep; every workgroup stores the same bytes), read 16 bytes per lane, unit and pending pivot per
 //     two rows during the sweep, single entries for the scalar chains with agent-scope loads;
 //   * a pivot row passes through registers 8 units per lane at a time (normalise, objective replica, pricing in one pass).
@@ -53,13 +53,22 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
            *rhsv = lav + rpw; // (nqv: what replaces a row's pivot-column entry, :25 / :36 -- one division per row and pivot, by one lane)
     int *tlist = reinterpret_cast<int *>(rhsv + rpw);
     const double flushed = __longlong_as_double((long long)FLUSHED);
-    // The pending normalised pivot rows: ONE scratch for all workgroups -- every workgroup computes the same rows from the same
-    // published bytes and stores them to the same place (identical values; a lane only ever reads back columns it stores
-    // itself, or, for the scalar chains, columns stored before its workgroup's barrier).  Private copies (256 x depth x 131 KB)
-    // did not stay in the L2s and were re-read from the Infinity Cache / HBM with every row.  Two sets, taken in turns from
-    // sweep to sweep: a workgroup that is through with its sweep may store the next pivot's row while another still sweeps
-    // (it cannot get further: deciding the pivot after that needs every workgroup's next candidate, published after its sweep).
-    double *prow0 = d.pend;
+    // The pending normalised pivot rows: one scratch PER XCD (d.pend: [8 XCDs][2 sets][depth][pitch]).  Every workgroup computes the
+    // same rows from the same published bytes; the workgroups of one XCD store them to the same place (identical values;
+    // a lane only ever reads back columns it stores itself, or, for the scalar chains, columns stored before its workgroup's
+    // barrier) and read them out of the L2 they share.  Private copies per workgroup (256 x depth x 131 KB) did not stay in
+    // the L2s; ONE copy for all XCDs is wrong with write-back stores -- the L2s are not coherent with each other, a dirty
+    // copy of an address from an earlier sweep generation lingering in another XCD's L2 was written back OVER the fresh row
+    // after this XCD had evicted it (tools/soak_delay.py, a 2 % dense tableau, case 1147: one workgroup's three touched rows
+    // wrong in the pivot row's 54 non-zero columns, not reproducible run to run) -- and costs 3-18 % with write-through
+    // stores.  The XCD is read from the hardware register: what matters is that workgroups with the same id share an L2,
+    // not which id a workgroup gets.  Two sets, taken in turns from sweep to sweep: a workgroup that is through with its
+    // sweep may store the next pivot's row while another still sweeps (it cannot get further: deciding the pivot after that
+    // needs every workgroup's next candidate, published after its sweep).
+    int xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+    double *const pend_xcd = d.pend + (size_t)(xcc & 7) * 2 * depth * pitch;
+    double *prow0 = pend_xcd;
 
     // (rows and scratch rows are addressed through a buffer descriptor of ONE row + a 32-bit lane offset, like sweep_kernel:
     // flat addressing held a 64-bit pair per unit, pivot and row in flight -- 192 spilled registers)
@@ -226,7 +235,7 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
         }
         npend = 0;
         pset ^= 1;
-        prow0 = d.pend + (size_t)pset * depth * pitch;
+        prow0 = pend_xcd + (size_t)pset * depth * pitch;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads(); // my rows are complete in memory (and the LDS arrays free) before anything reads them again
     };
@@ -481,12 +490,7 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
                     }
                 }
                 *reinterpret_cast<double2 *>(olds + c0) = ov;
-                // (write-through: the scratch is written by workgroups of all eight XCDs, whose L2s are not coherent with each other.
-                // With write-back stores a dirty copy of this address from an earlier sweep generation could linger in another
-                // XCD's L2 and be written back OVER the fresh row after this XCD had evicted it: re-read, the row was stale in
-                // some 128-byte lines -- found by tools/soak_delay.py on a 2 % dense tableau after 1147 cases, one workgroup's
-                // three touched rows wrong in the pivot row's 54 non-zero columns, not reproducible run to run)
-                row_st16<AUX_SC1>(rsrc_new, lane_off + 16 * T * (jb + j), 0, pn);
+                row_st16<AUX_PLAIN>(rsrc_new, lane_off + 16 * T * (jb + j), 0, pn);
             }
         }
         {

@@ -720,7 +720,7 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
             if (t->svar2.fn) {
                 t->sshmem2 = lds3;
                 d.delay_depth = depth3;
-                HIP_TRY(hipMalloc(&d.pend, sizeof(double) * 2 * (size_t)depth3 * d.pitch)); // (two sets of `depth` rows, shared by all workgroups)
+                HIP_TRY(hipMalloc(&d.pend, sizeof(double) * 8 * 2 * (size_t)depth3 * d.pitch)); // (per XCD: two sets of `depth` rows, shared by its workgroups)
                 t->stream3 = true;
             }
         }
