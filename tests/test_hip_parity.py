@@ -693,12 +693,15 @@ def test_inplace_path_terminal_statuses(nat, ctx, monkeypatch, kind, path, lds_r
     assert np.array_equal(got.view(np.int64), ref.view(np.int64))
 
 
-@pytest.mark.parametrize("path,lds_rows", TALL)
-def test_inplace_path_check_cycles(nat, ctx, oracle, monkeypatch, path, lds_rows):
-    """options.checkCycles through stream_kernel<.., true> (and the resident kernel with LDS rows): the tall narrow LP
-    solved to optimality with the verdict exchange in every pivot (no cycle), and a Chvatal-style cycling LP embedded
-    in a tall tableau (rows of zeros below it) that must stop "cycled" at the same pivot as the oracle."""
+@pytest.mark.parametrize("path,lds_rows,delay", [("inplace", "0", "1"), ("inplace", "0", "0"), ("resident", "1", "1")],
+                         ids=["stream3-check", "stream-check", "resident-lds"])
+def test_inplace_path_check_cycles(nat, ctx, oracle, monkeypatch, path, lds_rows, delay):
+    """options.checkCycles through stream3_kernel<.., true> (delayed row updates: a cycle verdict leaves with pivots
+    pending), stream_kernel<.., true> and the resident kernel with LDS rows: the tall narrow LP solved to optimality with
+    the verdict exchange in every pivot (no cycle), and a Chvatal-style cycling LP embedded in a tall tableau (rows of
+    zeros below it) that must stop "cycled" at the same pivot as the oracle."""
     monkeypatch.setenv("YALPS_HIP_LDS_ROWS", lds_rows)
+    monkeypatch.setenv("YALPS_HIP_DELAY", delay)
     M, N = 11000, 60
     w, h = N + 1, M + 1
     m = nat.dense_lp(M, N, 21)
@@ -716,6 +719,8 @@ def test_inplace_path_check_cycles(nat, ctx, oracle, monkeypatch, path, lds_rows
             t.upload(matrix, height, pos, var)
             status, result, npiv, _ = t.solve(**opts)
             assert t.info()["last_path"] == path, t.info()
+            if path == "inplace":
+                assert t.info()["inplace"].startswith("stream3_kernel" if delay == "1" else "stream_kernel"), t.info()
             got, gpos, gvar = t.download()
         finally:
             t.close()
@@ -725,13 +730,16 @@ def test_inplace_path_check_cycles(nat, ctx, oracle, monkeypatch, path, lds_rows
     assert est == "cycled"
 
 
-@pytest.mark.parametrize("M,N", [(1400, 8000), (300, 16000)])
-def test_check_cycles_on_wide_tableaux_launch_per_pivot(nat, ctx, M, N):
-    """checkCycles where no persistent kernel applies (4098+ columns beyond the on-chip size): DECIDE launches of
-    pivot_kernel<1024,4,..> + APPLY launches of wide_kernel, or (8194+ columns) the any-shape pair; 40 pivots
+@pytest.mark.parametrize("M,N,delay", [(1400, 8000, "0"), (300, 16000, "0"), (1400, 8000, "1"), (300, 16000, "1")])
+def test_check_cycles_on_wide_tableaux_launch_per_pivot(nat, ctx, monkeypatch, M, N, delay):
+    """checkCycles beyond the on-chip size.  With delayed updates switched off no persistent kernel applies by
+    default (4098+ columns): DECIDE launches of pivot_kernel<1024,4,..> + APPLY launches of wide_kernel, or
+    (8194+ columns) the any-shape pair.  With them on (the default) stream3_kernel<..,true> takes the shapes
+    that have 4+ rows per workgroup (1401 rows here; 301 rows stay on the launch-per-pivot path).  40 pivots
     against the numpy restatement (which
     has no hasCycle: no cycle can close within 40 pivots of these LPs, the check only has to stay silent)."""
     from tests import _np_simplex as NP
+    monkeypatch.setenv("YALPS_HIP_DELAY", delay)
     w, h = N + 1, M + 1
     m = nat.dense_lp(M, N, 13)
     m.reshape(h, w)[h // 3] *= -1.0
@@ -742,7 +750,10 @@ def test_check_cycles_on_wide_tableaux_launch_per_pivot(nat, ctx, M, N):
     try:
         t.upload(m, h, pos, var)
         status, result, npiv, _ = t.solve(max_pivots=40, check_cycles=True)
-        assert t.info()["last_path"] == ("generic" if N > 8192 else "streaming"), t.info()
+        if delay == "1" and M >= 1024:
+            assert t.info()["last_path"] == "inplace" and t.info()["inplace"] == "stream3_kernel<512,8>", t.info()
+        else:
+            assert t.info()["last_path"] == ("generic" if N > 8192 else "streaming"), t.info()
         got, gpos, gvar = t.download()
     finally:
         t.close()
@@ -870,7 +881,9 @@ SWEEP = [  # M, N, pivots, env, expected kernel, checkCycles
     (4400, 5500, 29, {"YALPS_HIP_DELAY_DEPTH": "5"}, "stream3_kernel<512,6>", False),
     (1400, 8000, 80, {"YALPS_HIP_SWEEP": "2", "YALPS_HIP_DELAY": "0"}, "sweep_kernel<512,8>", False),
     (2500, 5000, 60, {"YALPS_HIP_SWEEP": "2", "YALPS_HIP_SWEEP_NT": "1", "YALPS_HIP_DELAY": "0"}, "sweep_kernel<512,8,nt>", False),
-    (900, 7000, 60, {"YALPS_HIP_SWEEP": "2"}, "sweep_kernel<512,8>", True),
+    (900, 7000, 60, {"YALPS_HIP_SWEEP": "2", "YALPS_HIP_DELAY": "0"}, "sweep_kernel<512,8>", True),
+    (900, 7000, 61, {}, "stream3_kernel<512,8>", True),
+    (2100, 12345, 23, {}, "stream3_kernel<512,16>", True),
     # stream2_kernel (two pivots per sweep) with the same awkward data; its non-temporal forms; odd budgets
     (1400, 8000, 81, {"YALPS_HIP_DELAY_NT": "1", "YALPS_HIP_DELAY_KERNEL": "2"}, "stream2_kernel<512,8,nt>", False),
     (4300, 4000, 61, {"YALPS_HIP_DELAY_NT": "1", "YALPS_HIP_DELAY_KERNEL": "2"}, "stream2_kernel<1024,2,nt>", False),

@@ -25,3 +25,10 @@ PersistentTable yalps_stream3_table() {
                                                S3VARIANT(512, 2, 0), S3VARIANT(512, 2, 1), S3VARIANT(512, 1, 0), S3VARIANT(512, 1, 1)};
     return {kStream3, (int)(sizeof kStream3 / sizeof kStream3[0])};
 }
+#define S3CHECK(T, J, NT) {T, J, NT, reinterpret_cast<const void *>(&stream3_kernel<T, J, NT != 0, true>)}
+PersistentTable yalps_stream3_check_table() { // options.checkCycles
+    static const PersistentEntry kStream3Check[] = {S3CHECK(512, 16, 0), S3CHECK(512, 16, 1), S3CHECK(512, 8, 0), S3CHECK(512, 8, 1),
+                                                    S3CHECK(512, 6, 0), S3CHECK(512, 6, 1), S3CHECK(512, 4, 0), S3CHECK(512, 4, 1),
+                                                    S3CHECK(512, 2, 0), S3CHECK(512, 2, 1), S3CHECK(512, 1, 0), S3CHECK(512, 1, 1)};
+    return {kStream3Check, (int)(sizeof kStream3Check / sizeof kStream3Check[0])};
+}

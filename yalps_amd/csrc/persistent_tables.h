@@ -35,3 +35,4 @@ PersistentTable yalps_stream_check_table();
 PersistentTable yalps_stream2_table();
 // stream3_kernel<T, J, NT>: the same for rows of 8194 .. 16385 columns: objective replica in LDS, pending pivot rows in a global scratch
 PersistentTable yalps_stream3_table();
+PersistentTable yalps_stream3_check_table(); // ... with hasCycle (options.checkCycles)

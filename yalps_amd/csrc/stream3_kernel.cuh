@@ -15,12 +15,12 @@
 //     two rows during the sweep, single entries for the scalar chains with agent-scope loads;
 //   * a pivot row passes through registers 8 units per lane at a time (normalise, objective replica, pricing in one pass).
 // ------------------------------------------------------------------------------------------
-template <int T, int J, bool NT>
+template <int T, int J, bool NT, bool CHECK = false>
 __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chunk) {
     __shared__ double sk[2][16];
     __shared__ int si[2][16];
     __shared__ double sh_q, sh_c0; // quotient; objective-row entry of the pivot column
-    __shared__ int sh_fail, sh_nt;
+    __shared__ int sh_fail, sh_nt, sh_flag, sh_verdict;
     constexpr int MAXD = 8;
     __shared__ int sh_pl[MAXD], sh_pc[MAXD]; // the pending pivots, oldest first: my slot of the pivot row (-1: not mine), pivot column (mat index)
     __shared__ int sh_fast[MAXD][T / 64];       // per wave: nothing of its slice of that pivot row was flushed (:31 select-free path)
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
     int phase = Sin->phase;
     double iter = Sin->iter;
     int64_t pivots = Sin->pivots;
-    const int64_t hist_len = Sin->hist_len;
+    int64_t hist_len = Sin->hist_len; // checkCycles: pivots recorded in the current phase (src/simplex.ts:67,107)
     int slot = 0;
     const int rpw = (d.hcap + NB - 1) / NB;
     const int my_rows = b < h ? (h - 1 - b) / NB + 1 : 0;
@@ -370,6 +370,7 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
             if (phase == 1) { // :120 phase 1 is over: same tableau, now the min-ratio exchange
                 phase = 2;
                 iter = 0.0;
+                hist_len = 0;
                 check();
                 if (!stop) {
                     if (la > 0)
@@ -424,6 +425,43 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
                 continue;
             }
             col = e.i;
+        }
+        if constexpr (CHECK) { // :98,137 hasCycle before the pivot: workgroup 0 (it maintains the basis) decides for everybody
+            int cycled = 0;
+            if (b == 0) { // (the basis is updated by my lane 0 behind my own barriers; agent-scope loads read it at L2)
+                const int leaving = __hip_atomic_load(d.var + w + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int entering = __hip_atomic_load(d.var + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                cycled = has_cycle(C, hist_len, leaving, entering, &sh_flag) ? 1 : 0;
+                if (tid == 0)
+                    __hip_atomic_store(d.rc_verdict + par, ((unsigned long long)epoch << 32) | (unsigned)cycled, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                if (tid == 0) {
+                    unsigned long long v = 0;
+                    unsigned spins = 0;
+                    unsigned long long spin_t0 = 0;
+                    for (;;) {
+                        v = __hip_atomic_load(d.rc_verdict + par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((unsigned)(v >> 32) == epoch) break;
+                        if (spin_expired(spins, spin_t0, d.rc_err)) {
+                            sh_fail = 1;
+                            __hip_atomic_store(d.rc_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    sh_verdict = (int)(unsigned)v;
+                }
+                __syncthreads();
+                if (sh_fail) return;
+                cycled = sh_verdict;
+            }
+            hist_len += 1;
+            if (cycled) { // ["cycled", NaN]: this pivot is not carried out; the pending ones are, on the way out
+                term = YALPS_CYCLED;
+                stop = true;
+                continue;
+            }
         }
         // ---------------- pivot (src/simplex.ts:5-39): it becomes pending pivot number npend ---------------------------
         const int colx = col - 1;
@@ -516,8 +554,8 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
         }
         if (b == 0 && tid == 0) { // basis bookkeeping, :7-12 (off the critical path)
             const int leaving = d.var[w + row], entering = d.var[col];
-            d.var[w + row] = entering;
-            d.var[col] = leaving;
+            __hip_atomic_store(d.var + w + row, entering, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(d.var + col, leaving, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             d.pos[leaving] = col;
             d.pos[entering] = w + row;
         }

@@ -142,6 +142,7 @@ const std::vector<RVariant> kSweep = variants_of({yalps_sweep_table()});
 const std::vector<RVariant> kSweepCheck = variants_of({yalps_sweep_check_table()});
 const std::vector<RVariant> kStream2 = variants_of({yalps_stream2_table()}); // (R = non-temporal row traffic)
 const std::vector<RVariant> kStream3 = variants_of({yalps_stream3_table()});
+const std::vector<RVariant> kStream3Check = variants_of({yalps_stream3_check_table()});
 constexpr size_t SWEEP_BEYOND_CACHE = 200u << 20; // tableau bytes from which row traffic goes non-temporal (Infinity Cache: 256 MiB)
 constexpr int RESIDENT_CHUNK = 4096; // pivots per launch of the resident kernel (bounds its run time)
 
@@ -271,7 +272,9 @@ struct yalps_tableau {
     RVariant svar{0, 0, 0, nullptr}; // stream_kernel variant (persistent, in place)
     RVariant svar_check{0, 0, 0, nullptr}; // the same with hasCycle (options.checkCycles)
     bool sweep = false;                    // svar / svar_check are sweep_kernel variants
-    RVariant svar2{0, 0, 0, nullptr};      // stream2_kernel variant: two pivots per sweep (taken without checkCycles; YALPS_HIP_DELAY=0: never)
+    RVariant svar2{0, 0, 0, nullptr};      // stream3_kernel / stream2_kernel variant: delayed row updates (YALPS_HIP_DELAY=0: never)
+    RVariant svar2_check{0, 0, 0, nullptr}; // ... with hasCycle (stream3_kernel only)
+    bool sattr2_check = false;
     size_t sshmem2 = 0;
     bool sattr2 = false;
     bool last_delayed = true; // what the last in-place solve ran (before the first one: what it would run)
@@ -717,6 +720,9 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
             if (lds3 <= 150 * 1024)
                 for (const RVariant &v : kStream3)
                     if (v.T == 512 && v.J == sJ && v.R == want_nt2) t->svar2 = v;
+            if (t->svar2.fn)
+                for (const RVariant &v : kStream3Check)
+                    if (v.T == 512 && v.J == sJ && v.R == want_nt2) t->svar2_check = v;
             if (t->svar2.fn) {
                 t->sshmem2 = lds3;
                 d.delay_depth = depth3;
@@ -1234,7 +1240,7 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
     const bool resident_on = c->resident && (c->resident_skip == 0 || --c->resident_skip == 0);
     const bool inplace_on = c->inplace && (c->inplace_skip == 0 || --c->inplace_skip == 0);
     // (rows of 8194 .. 16385 columns: sweep_kernel where it applies, else the any-shape pair)
-    const bool sweep_ok = t->sweep && t->d.nshards == 1 && inplace_on && (checkCycles ? t->svar_check.fn : t->svar.fn);
+    const bool sweep_ok = t->sweep && t->d.nshards == 1 && inplace_on && (checkCycles ? (t->svar_check.fn || t->svar2_check.fn) : t->svar.fn != nullptr);
     if (t->generic || (t->prefer_generic && t->d.nshards == 1 && !sweep_ok))
         return solve_generic(t, precision, maxPivots, checkCycles, result_out, pivots_out, gpu_ms_out);
     const int which = checkCycles ? 1 : 0;
@@ -1254,13 +1260,15 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
     for (int attempt = 0; attempt < 2 && !finished; attempt++) {
         const bool persistent_ok = t->d.nshards == 1;
         const bool use_resident = persistent_ok && resident_on && c->resident_skip == 0 && t->rvar.fn; // (checkCycles: one more exchange per pivot)
-        const bool use_stream = persistent_ok && !use_resident && inplace_on && c->inplace_skip == 0 && (checkCycles ? t->svar_check.fn : t->svar.fn);
+        const bool use_stream = persistent_ok && !use_resident && inplace_on && c->inplace_skip == 0 &&
+                                (checkCycles ? (t->svar_check.fn || t->svar2_check.fn) : t->svar.fn != nullptr);
         if (!use_resident && !use_stream) break;
         const bool in_place = use_stream;
-        const bool delayed = in_place && !checkCycles && t->svar2.fn; // stream2_kernel: two pivots per sweep
+        const bool delayed = in_place && (checkCycles ? t->svar2_check.fn : t->svar2.fn); // stream3_kernel / stream2_kernel: several pivots per sweep
         if (in_place) t->last_delayed = delayed;
-        const RVariant &pv = delayed ? t->svar2 : in_place ? (checkCycles ? t->svar_check : t->svar) : t->rvar_tag.fn ? t->rvar_tag : t->rvar;
-        bool &sattr = delayed ? t->sattr2 : checkCycles ? t->sattr_check : t->sattr;
+        const RVariant &pv = delayed ? (checkCycles ? t->svar2_check : t->svar2)
+                             : in_place ? (checkCycles ? t->svar_check : t->svar) : t->rvar_tag.fn ? t->rvar_tag : t->rvar;
+        bool &sattr = delayed ? (checkCycles ? t->sattr2_check : t->sattr2) : checkCycles ? t->sattr_check : t->sattr;
         const size_t shmem = delayed ? t->sshmem2 : in_place ? t->sshmem : t->rx_shmem ? t->rx_shmem : sizeof(int32_t) * 2 * (size_t)t->perm_len;
         if (in_place ? !sattr : shmem != t->rshmem) {
             if (shmem > 48 * 1024)
@@ -1281,7 +1289,7 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
                                  in_place ? "stream_kernel" : "resident_kernel", pv.T, pv.J, pv.R, t->nb, c->num_cus, per_cu);
                 t->occupancy_warned = true;
                 if (delayed)
-                    t->svar2.fn = nullptr;
+                    t->svar2.fn = t->svar2_check.fn = nullptr;
                 else if (in_place)
                     t->svar.fn = t->svar_check.fn = nullptr;
                 else
