@@ -1,8 +1,9 @@
 """Worker of the multi-process row-sharded tests: one rank of a gloo (or nccl) group.
-usage: python -m tests._shard_worker <numpy|hip|hip-native> <M> <N> <seed> <out.npz> [max_pivots [digest]]
+usage: python -m tests._shard_worker <numpy|hip|hip-native> <M> <N> <seed> <out.npz> [max_pivots [digest|phase1]]
 (hip-native: the library's own loop, yalps_shard_run, with the host transport carried by gloo)
 (RANK/WORLD_SIZE/MASTER_* in env).  `digest`: instead of the assembled tableau, rank 0 saves the SHA-256 of the
-objective row and of every rank's block of rows (full-size runs: the tableau is 2.1 GB)."""
+objective row and of every rank's block of rows (full-size runs: the tableau is 2.1 GB).  `phase1`: the input of
+tests/test_hip_parity.py's sweep cases (one row "-a x <= -b", exact zeros, degenerate rows) instead of the seed's parity."""
 import os
 import sys
 
@@ -26,6 +27,11 @@ def main():
     m = _oracle.load().dense_lp(M, N, seed)
     if digest:  # (the full-size test's input: one row "-a x <= -b", so that the first pivot is a phase-1 pivot)
         m.reshape(h, w)[h // 3] *= -1.0
+    elif len(sys.argv) > 7 and sys.argv[7] == "phase1":
+        A = m.reshape(h, w)
+        A[h // 3] *= -1.0
+        A[5::7, 3::5] = 0.0  # exact zeros: untouched rows, flushed pivot-row entries
+        A[2::9, 0] = 0.0     # degenerate rows
     elif seed % 2:  # make some right-hand sides negative so that phase 1 runs too
         m.reshape(h, w)[1::3, 0] *= -0.05
     bounds = sharded.partition(h, world)
@@ -45,6 +51,7 @@ def main():
     else:
         comm = sharded.TorchComm()
         status, result, pivots = sharded.sharded_simplex(ops, comm, max_pivots=max_pivots, check_every=8 if max_pivots > 8 else 1)
+    kernel = "numpy" if kind == "numpy" else ops.tab.info()["streaming"]
     lm, pos, var = ops.download()
     if digest:
         import hashlib
@@ -54,7 +61,7 @@ def main():
         dist.all_gather_object(parts, mine)
         if rank == 0:
             np.savez(out, row0=[p[0] for p in parts], blocks=[p[1] for p in parts], bounds=bounds, pos=pos, var=var,
-                     status=status, result=result, pivots=pivots)
+                     status=status, result=result, pivots=pivots, kernel=kernel)
         ops.close()
         dist.barrier()
         dist.destroy_process_group()
@@ -69,7 +76,7 @@ def main():
             if r == 0:
                 full[0] = pm[0]
             full[lo:hi] = pm[1:]
-        np.savez(out, matrix=full.reshape(-1), pos=pos, var=var, status=status, result=result, pivots=pivots)
+        np.savez(out, matrix=full.reshape(-1), pos=pos, var=var, status=status, result=result, pivots=pivots, kernel=kernel)
     ops.close()
     dist.barrier()
     dist.destroy_process_group()

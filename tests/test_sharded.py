@@ -19,28 +19,33 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def run_world(kind, world, M, N, seed, tmp_path):
+def run_world(kind, world, M, N, seed, tmp_path, extra=()):
     out = str(tmp_path / f"res_{kind}_{world}_{M}_{N}_{seed}.npz")
     port = _free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, "-m", "tests._shard_worker", kind, str(M), str(N), str(seed), out],
+        procs.append(subprocess.Popen([sys.executable, "-m", "tests._shard_worker", kind, str(M), str(N), str(seed), out] + [str(a) for a in extra],
                                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)
     return np.load(out)
 
 
-def check_against_oracle(oracle, res, M, N, seed):
+def check_against_oracle(oracle, res, M, N, seed, max_pivots=np.inf, phase1=False):
     w, h = N + 1, M + 1
     m = oracle.dense_lp(M, N, seed)
-    if seed % 2:
+    if phase1:  # (tests/_shard_worker.py, `phase1`)
+        A = m.reshape(h, w)
+        A[h // 3] *= -1.0
+        A[5::7, 3::5] = 0.0
+        A[2::9, 0] = 0.0
+    elif seed % 2:
         m.reshape(h, w)[1::3, 0] *= -0.05
     pos = np.arange(w + h, dtype=np.int32)
     var = pos.copy()
-    status, result, npiv, _ = oracle.simplex(m, w, h, pos, var, max_pivots=np.inf)
+    status, result, npiv, _ = oracle.simplex(m, w, h, pos, var, max_pivots=max_pivots)
     assert str(res["status"]) == status and int(res["pivots"]) == npiv
     assert G.same_number(float(res["result"]), result)
     assert np.array_equal(res["pos"], pos) and np.array_equal(res["var"], var)
@@ -71,6 +76,35 @@ def test_sharded_hip_steps(oracle, tmp_path, world, M, N, seed):
     (<1024,2,in place>, <512,16,in place>: several waves per row, rows updated where they are)."""
     res = run_world("hip", world, M, N, seed, tmp_path)
     check_against_oracle(oracle, res, M, N, seed)
+
+
+DELAYED = [
+    # forced onto shards with one row per workgroup (the switch is read by yalps_tableau_set_shard): whole solves, phase 1
+    # first, depths 3 / 4 / 8, <512,4> / <512,6> / <512,16>, two and three ranks, both drivers
+    ("hip", 2, 120, 3000, 6, None, False, {"YALPS_HIP_DELAY_MIN_ROWS": "1"}, "dshard_kernel<512,4>,delay_depth:4"),
+    ("hip", 3, 100, 9000, 8, None, True, {"YALPS_HIP_DELAY_MIN_ROWS": "1", "YALPS_HIP_DELAY_DEPTH": "3"}, "dshard_kernel<512,16>,delay_depth:3"),
+    ("hip-native", 2, 150, 6000, 11, None, True, {"YALPS_HIP_DELAY_MIN_ROWS": "1", "YALPS_HIP_DELAY_DEPTH": "8"}, "dshard_kernel<512,6>,delay_depth:8"),
+    ("hip-native", 3, 90, 2500, 4, None, True, {"YALPS_HIP_DELAY_MIN_ROWS": "1", "YALPS_HIP_DELAY_DEPTH": "2"}, "dshard_kernel<512,4>,delay_depth:2"),
+    # what takes them by default (4+ rows per workgroup): 1150 / 767 rows per rank; budgets that end between two sweeps
+    ("hip", 2, 2300, 4200, 6, 150, False, {}, "dshard_kernel<512,6>,delay_depth:4"),
+    ("hip-native", 3, 2300, 4200, 5, 131, True, {}, "dshard_kernel<512,6>,delay_depth:4"),
+    # ... and the same shard one sweep per pivot, by request
+    ("hip", 2, 2300, 4200, 6, 37, False, {"YALPS_HIP_SHARD_DELAY": "0"}, "wide_kernel<1024,4>"),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,world,M,N,seed,budget,phase1,env,kernel", DELAYED)
+def test_sharded_delayed_row_updates(oracle, tmp_path, monkeypatch, kind, world, M, N, seed, budget, phase1, env, kernel):
+    """dshard_kernel / dshard_select_kernel: a pivot costs a shard its scalars, the rows are swept once per `depth` pivots
+    and on the way out; the candidate rows travel with the pending pivots applied.  Status, result, pivot count, basis
+    and every bit of the assembled tableau against the oracle."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    extra = ["inf" if budget is None else budget] + (["phase1"] if phase1 else [])
+    res = run_world(kind, world, M, N, seed, tmp_path, extra)
+    assert str(res["kernel"]) == kernel
+    check_against_oracle(oracle, res, M, N, seed, max_pivots=np.inf if budget is None else float(budget), phase1=phase1)
 
 
 @pytest.mark.gpu

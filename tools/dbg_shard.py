@@ -15,8 +15,11 @@ M, N, seed, piv = (int(a) for a in sys.argv[1:5])
 w, h = N + 1, M + 1
 orc = _oracle.load()
 m = orc.dense_lp(M, N, seed)
-if seed % 2:
-    m.reshape(h, w)[1::3, 0] *= -0.05
+if seed % 2:  # "-a x <= -b": phase 1 first; exact zeros (untouched rows, flushed pivot-row entries); degenerate rows
+    A = m.reshape(h, w)
+    A[h // 3] *= -1.0
+    A[5::7, 3::5] = 0.0
+    A[2::9, 0] = 0.0
 ident = np.arange(w + h, dtype=np.int32)
 ref, rpos, rvar = m.copy(), ident.copy(), ident.copy()
 est, eres, epiv, _ = orc.simplex(ref, w, h, rpos, rvar, max_pivots=float(piv))

@@ -44,6 +44,15 @@ struct alignas(16) YState {
     int64_t pivots; // total over both phases
 };
 
+// Row shards with delayed row updates (dshard_kernel.cuh): what is pending between two launches, ping-ponged like YState.
+struct alignas(16) DelayState {
+    int32_t npend;     // pivots decided whose eliminations have not been carried out on this rank's rows
+    int32_t lav_valid; // d.dlav holds my rows' entries of column YState::la as they are now
+    int32_t pad_[2];
+    int32_t pl[8]; // per pending pivot, oldest first: the pivot row as a LOCAL row of this rank (-1: another rank's)
+    int32_t pc[8]; // ... its pivot column (mat index)
+};
+
 struct alignas(16) Part {
     double key;
     int32_t idx;
@@ -90,6 +99,11 @@ struct Desc {
     // row shards swept IN PLACE (wide_kernel<.., true, ..>): the objective row is the one row every workgroup reads while
     // its owner rewrites it, so it alone stays ping-ponged, as two replicas [pitch] beside the tableau
     double *obj[2];
+    // row shards with delayed row updates (dshard_kernel.cuh; d.delay_depth pivots per sweep): the pending normalised pivot
+    // rows [depth][pitch], my rows' entries of their pivot columns and what replaces them [depth][hcap] each, my rows'
+    // entries of the next entering column [hcap], the pending pivots' rows / columns [2] by launch parity
+    double *dpend, *dcolv, *dnqv, *dlav;
+    DelayState *dstate;
     // diagnostic build only (-DYALPS_STAMPS, never the shipped library): [nb][STAMP_WORDS] per-workgroup stage sums in
     // shader cycles, written once when a persistent launch ends; no kernel reads it
     unsigned long long *dbg;

@@ -36,3 +36,7 @@ PersistentTable yalps_stream2_table();
 // stream3_kernel<T, J, NT>: the same for rows of 8194 .. 16385 columns: objective replica in LDS, pending pivot rows in a global scratch
 PersistentTable yalps_stream3_table();
 PersistentTable yalps_stream3_check_table(); // ... with hasCycle (options.checkCycles)
+// dshard_kernel<T, J, NT>: one pivot of a row shard with delayed row updates -- __global__ void (Desc, int parity, int, int,
+// const double *gather), launch-per-pivot like wide_kernel in MODE_SHARD; R = NT.  dshard_select_kernel: (Desc, int parity, double *send)
+PersistentTable yalps_dshard_table();
+const void *yalps_dshard_select_fn();

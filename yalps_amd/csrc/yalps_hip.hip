@@ -143,6 +143,7 @@ const std::vector<RVariant> kSweepCheck = variants_of({yalps_sweep_check_table()
 const std::vector<RVariant> kStream2 = variants_of({yalps_stream2_table()}); // (R = non-temporal row traffic)
 const std::vector<RVariant> kStream3 = variants_of({yalps_stream3_table()});
 const std::vector<RVariant> kStream3Check = variants_of({yalps_stream3_check_table()});
+const std::vector<RVariant> kDshard = variants_of({yalps_dshard_table()}); // (launch-per-pivot: (Desc, parity, mode, force, gather); R = non-temporal row traffic)
 constexpr size_t SWEEP_BEYOND_CACHE = 200u << 20; // tableau bytes from which row traffic goes non-temporal (Infinity Cache: 256 MiB)
 constexpr int RESIDENT_CHUNK = 4096; // pivots per launch of the resident kernel (bounds its run time)
 
@@ -301,6 +302,10 @@ struct yalps_tableau {
     int32_t perm_len = 0; // entries of pos / var (width + GLOBAL height)
     Variant var{};
     int wT_inplace = 0;
+    KernelFn dfn = nullptr;         // row shard with delayed row updates: dshard_kernel<512, dJ, nt> (d.dpend / dcolv / dnqv / dlav / dstate)
+    int dJ = 0, dnt = 0;
+    size_t dshmem = 0;
+    void *dsh_block = nullptr;      // ... its arrays, one allocation
     KernelFn wfn_inplace = nullptr; // row shard: wide_kernel<.., true, nt> for the MODE_SHARD launches (in place; d.obj holds the objective replicas)
     KernelFn wfn = nullptr; // wide_kernel variant used for FUSED / APPLY / SHARD launches when the tableau is
                             // too wide or too tall for pivot_kernel's register-resident batches
@@ -343,7 +348,9 @@ void launch_one(yalps_tableau *t, int parity, int mode, int force, const double 
 // the elimination step of a row shard (MODE_SHARD): in place where the shard has the kernel for it
 void launch_shard(yalps_tableau *t, const double *gathered) {
     const int force = t->ctx->nt_stores ? 64 : 0;
-    if (t->wfn_inplace)
+    if (t->dfn)
+        t->dfn<<<dim3(t->nb), dim3(512), t->dshmem, t->ctx->stream>>>(t->d, t->shard_parity, MODE_SHARD, force, gathered);
+    else if (t->wfn_inplace)
         t->wfn_inplace<<<dim3(t->nb), dim3(t->wT_inplace), t->wshmem, t->ctx->stream>>>(t->d, t->shard_parity, MODE_SHARD, force, gathered);
     else
         launch_one(t, t->shard_parity, MODE_SHARD, force, gathered);
@@ -823,7 +830,7 @@ void yalps_tableau_destroy(yalps_tableau *t) {
     void *bufs[] = {d.mat[0], d.mat[1], d.rhs[0], d.rhs[1], t->perm_block ? nullptr : d.pos, t->perm_block ? nullptr : d.var, t->perm_block,
                     t->ctl_block ? nullptr : d.st, t->ctl_block ? nullptr : d.cst, t->ctl_block, d.rc_rows[0], d.rc_rows[1], t->perm_backup,
                     d.rc_key[0], d.rc_key[1], d.gen_prow, d.gen_scal, d.part_ratio[0], d.part_ratio[1], d.part_rhs[0], d.part_rhs[1],
-                    t->hist[0], t->hist[1], t->cells, d.dbg, d.obj[0], d.pend};
+                    t->hist[0], t->hist[1], t->cells, d.dbg, d.obj[0], d.pend, t->dsh_block};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (t->host_state) (void)hipHostFree(t->host_state);
@@ -847,7 +854,9 @@ int32_t yalps_tableau_info(const yalps_tableau *t, char *buf, int32_t len) {
     else if (t->svar.fn)
         std::snprintf(inp, sizeof inp, "%s_kernel<%d,%d%s>", t->sweep ? "sweep" : "stream", t->svar.T, t->svar.J, t->sweep && t->d.sw_nt ? ",nt" : "");
     char str[64];
-    if (t->wfn)
+    if (t->dfn)
+        std::snprintf(str, sizeof str, "dshard_kernel<512,%d%s>,delay_depth:%d", t->dJ, t->dnt ? ",nt" : "", t->d.delay_depth);
+    else if (t->wfn)
         std::snprintf(str, sizeof str, "wide_kernel<%d,%d>", t->var.T, t->var.J);
     else
         std::snprintf(str, sizeof str, "pivot_kernel<%d,%d,%d>", t->var.T, t->var.J, t->var.R);
@@ -1720,6 +1729,42 @@ int32_t yalps_tableau_set_shard(yalps_tableau *t, int32_t rank, int32_t nranks, 
             }
         }
     }
+    // Delayed row updates (dshard_kernel.cuh): a pivot costs the shard its scalars, the sweep comes once per `depth` pivots.
+    // Shards swept in place with at least YALPS_HIP_DELAY_MIN_ROWS rows per workgroup; YALPS_HIP_SHARD_DELAY=0: one sweep per pivot.
+    t->dfn = nullptr;
+    {
+        const int rows_per_block = (d.hcap + t->nb - 1) / t->nb, units = d.pitch / 2;
+        int dJ = 0;
+        for (int cand : {1, 2, 4, 6, 8, 16})
+            if (!dJ && 512 * cand >= units) dJ = cand;
+        if (t->wfn_inplace && dJ && env_int("YALPS_HIP_SHARD_DELAY", 1) && rows_per_block >= env_int("YALPS_HIP_DELAY_MIN_ROWS", 4)) {
+            const int depth = std::min(8, std::max(2, env_int("YALPS_HIP_DELAY_DEPTH", std::max(4, (rows_per_block + 1) / 3))));
+            const bool nt = env_int("YALPS_HIP_SHARD_NT", sizeof(double) * (size_t)d.pitch * (size_t)t->height > SWEEP_BEYOND_CACHE ? 1 : 0) != 0;
+            const size_t lds = sizeof(double) * (2 * (size_t)depth + 2) * (size_t)rows_per_block + sizeof(int32_t) * (size_t)rows_per_block;
+            if (lds <= 150 * 1024)
+                for (const RVariant &v : kDshard)
+                    if (v.T == 512 && v.J == dJ && v.R == (nt ? 1 : 0)) t->dfn = reinterpret_cast<KernelFn>(v.fn);
+            if (t->dfn) {
+                if (lds > 48 * 1024)
+                    if (int rc = allow_big_lds(t->ctx->device, reinterpret_cast<const void *>(t->dfn))) return rc;
+                t->dshmem = lds;
+                t->dJ = dJ;
+                t->dnt = nt ? 1 : 0;
+                d.delay_depth = depth;
+                if (t->dsh_block) HIP_TRY(hipFree(t->dsh_block));
+                t->dsh_block = nullptr;
+                const size_t hc = ((size_t)d.hcap + 1) / 2 * 2; // (16-byte parts)
+                const size_t doubles = (size_t)depth * d.pitch + 2 * (size_t)depth * hc + hc;
+                HIP_TRY(hipMalloc(&t->dsh_block, sizeof(double) * doubles + 2 * sizeof(DelayState)));
+                HIP_TRY(hipMemsetAsync(t->dsh_block, 0, sizeof(double) * doubles + 2 * sizeof(DelayState), s));
+                d.dpend = static_cast<double *>(t->dsh_block);
+                d.dcolv = d.dpend + (size_t)depth * d.pitch;
+                d.dnqv = d.dcolv + (size_t)depth * hc;
+                d.dlav = d.dnqv + (size_t)depth * hc;
+                d.dstate = reinterpret_cast<DelayState *>(d.dlav + hc);
+            }
+        }
+    }
     // graphs captured for the unsharded tableau hold the old Desc
     for (int k = 0; k < 2; k++) {
         if (t->graph_exec[k]) (void)hipGraphExecDestroy(t->graph_exec[k]);
@@ -1740,6 +1785,7 @@ int32_t yalps_shard_begin(yalps_tableau *t, double precision, double maxPivots) 
     launch_one(t, 0, MODE_FUSED, 0); // bootstrap scan: emits this rank's first partials
     HIP_TRY(hipGetLastError());
     t->shard_parity = 1;
+    if (t->dfn) HIP_TRY(hipMemsetAsync(t->d.dstate, 0, 2 * sizeof(DelayState), t->ctx->stream)); // nothing pending
     if (t->wfn_inplace) // (the scan left the tableau in buffer 1 and the partials in set 1: the first in-place launch reads replica 1)
         HIP_TRY(hipMemcpyAsync(t->d.obj[1], t->d.mat[1], sizeof(double) * (size_t)t->d.pitch, hipMemcpyDeviceToDevice, t->ctx->stream));
     return 0;
@@ -1750,9 +1796,18 @@ static int shard_select_blocks(const yalps_tableau *t) { // 16-byte units of the
     return blocks < 1 ? 1 : blocks > 64 ? 64 : blocks;
 }
 
+// this rank's candidates + their rows into its slot of the all-gather (delayed row updates: with the pending pivots applied)
+static void launch_select(yalps_tableau *t, double *send) {
+    using SelectFn = void (*)(Desc, int, double *);
+    if (t->dfn)
+        reinterpret_cast<SelectFn>(const_cast<void *>(yalps_dshard_select_fn()))<<<dim3(shard_select_blocks(t)), dim3(1024), 0, t->ctx->stream>>>(t->d, t->shard_parity, send);
+    else
+        shard_select_kernel<<<dim3(shard_select_blocks(t)), dim3(1024), 0, t->ctx->stream>>>(t->d, t->shard_parity, send);
+}
+
 int32_t yalps_shard_select(yalps_tableau *t, double *send_dev) {
     if (!t || !send_dev) return fail(YALPS_E_ARG, "yalps_shard_select: bad argument");
-    shard_select_kernel<<<dim3(shard_select_blocks(t)), dim3(1024), 0, t->ctx->stream>>>(t->d, t->shard_parity, send_dev);
+    launch_select(t, send_dev);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1930,7 +1985,7 @@ static int comm_reserve(yalps_comm *c, size_t slot) {
 // one pivot of the sharded solve on the context's stream: my candidates, the exchange, the elimination
 static int shard_step(yalps_tableau *t, yalps_comm *c, size_t slot) {
     hipStream_t s = t->ctx->stream;
-    shard_select_kernel<<<dim3(shard_select_blocks(t)), dim3(1024), 0, s>>>(t->d, t->shard_parity, c->send);
+    launch_select(t, c->send);
     if (c->nccl) {
         NCCL_TRY(rccl().AllGather(c->send, c->recv, slot, NCCL_FLOAT64, c->nccl, s));
     } else { // host transport: down, the host's own all-gather, up (a test / bring-up path: one wait per pivot)
