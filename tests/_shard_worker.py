@@ -3,7 +3,7 @@ usage: python -m tests._shard_worker <numpy|hip|hip-native> <M> <N> <seed> <out.
 (hip-native: the library's own loop, yalps_shard_run, with the host transport carried by gloo)
 (RANK/WORLD_SIZE/MASTER_* in env).  `digest`: instead of the assembled tableau, rank 0 saves the SHA-256 of the
 objective row and of every rank's block of rows (full-size runs: the tableau is 2.1 GB).  `phase1`: the input of
-tests/test_hip_parity.py's sweep cases (one row "-a x <= -b", exact zeros, degenerate rows) instead of the seed's parity."""
+tests/test_hip_parity.py's sweep cases (one row "-a x <= -b", exact zeros) instead of the seed's parity."""
 import os
 import sys
 
@@ -31,7 +31,6 @@ def main():
         A = m.reshape(h, w)
         A[h // 3] *= -1.0
         A[5::7, 3::5] = 0.0  # exact zeros: untouched rows, flushed pivot-row entries
-        A[2::9, 0] = 0.0     # degenerate rows
     elif seed % 2:  # make some right-hand sides negative so that phase 1 runs too
         m.reshape(h, w)[1::3, 0] *= -0.05
     bounds = sharded.partition(h, world)
