@@ -118,6 +118,9 @@ def main():
     ap.add_argument("--sweep-launches", type=int, default=400)
     ap.add_argument("--workload", choices=("replicas", "sharded"), default="replicas")
     ap.add_argument("--pivots-per-step", type=int, default=256, help="sharded workload: pivots per step")
+    ap.add_argument("--shard-rows", type=int, default=0,
+                    help="sharded workload: M of dense-LP(M,size,seed) instead of size (one rank's share of a larger world, "
+                         "measured on one GPU: e.g. 2048 rows of 16384 columns = a rank of 8)")
     args = ap.parse_args()
 
     import torch
@@ -295,7 +298,8 @@ def bench_sharded(args, torch, dist, rank, local_rank, world):
     library's (yalps_shard_run): select kernel, ncclAllGather (RCCL over xGMI) on the same stream, apply kernel, a batch
     of pivots per hipGraph replay -- Python is entered once per timed region."""
     from yalps_amd import _native, sharded
-    M = N = args.size
+    N = args.size
+    M = args.shard_rows if args.shard_rows > 0 else N
     w, h = N + 1, M + 1
     m = _native.dense_lp(M, N, 42)
     bounds = sharded.partition(h, world)

@@ -81,13 +81,13 @@ DELAYED = [
     # forced onto shards with one row per workgroup (the switch is read by yalps_tableau_set_shard): a whole solve; phase 1
     # first with pivot budgets (these LPs cycle without the budget), depths 2 / 3 / 4 / 8, <512,4> / <512,6> / <512,16>,
     # two and three ranks, both drivers
-    ("hip", 2, 120, 3000, 6, None, False, {"YALPS_HIP_DELAY_MIN_ROWS": "1"}, "dshard_kernel<512,4>,delay_depth:4"),
+    ("hip", 2, 120, 3000, 6, None, False, {"YALPS_HIP_DELAY_MIN_ROWS": "1", "YALPS_HIP_DELAY_DEPTH": "4"}, "dshard_kernel<512,4>,delay_depth:4"),
     ("hip", 3, 100, 9000, 8, 401, True, {"YALPS_HIP_DELAY_MIN_ROWS": "1", "YALPS_HIP_DELAY_DEPTH": "3"}, "dshard_kernel<512,16>,delay_depth:3"),
     ("hip-native", 2, 150, 6000, 11, 397, True, {"YALPS_HIP_DELAY_MIN_ROWS": "1", "YALPS_HIP_DELAY_DEPTH": "8"}, "dshard_kernel<512,6>,delay_depth:8"),
     ("hip-native", 3, 90, 3500, 4, 211, True, {"YALPS_HIP_DELAY_MIN_ROWS": "1", "YALPS_HIP_DELAY_DEPTH": "2"}, "dshard_kernel<512,4>,delay_depth:2"),
     # what takes them by default (4+ rows per workgroup): 1150 / 1100 rows per rank; budgets that end between two sweeps
-    ("hip", 2, 2300, 4200, 6, 150, False, {}, "dshard_kernel<512,6>,delay_depth:4"),
-    ("hip-native", 3, 3300, 4200, 5, 131, True, {}, "dshard_kernel<512,6>,delay_depth:4"),
+    ("hip", 2, 2300, 4200, 6, 150, False, {}, "dshard_kernel<512,6>,delay_depth:8"),
+    ("hip-native", 3, 3300, 4200, 5, 131, True, {}, "dshard_kernel<512,6>,delay_depth:8"),
     # ... and the same shard one sweep per pivot, by request
     ("hip", 2, 2300, 4200, 6, 37, False, {"YALPS_HIP_SHARD_DELAY": "0"}, "wide_kernel<1024,4>"),
 ]

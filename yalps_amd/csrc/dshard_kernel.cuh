@@ -135,7 +135,10 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
         __syncthreads();
     };
     // the pending pivots applied to (up to) RB half-rows held in registers: units [u0, u0 + JH) of my row slots ri[0 .. cnt)
-    constexpr int JH = J > 8 ? 8 : J, RB = J > 8 ? 2 : 3;
+    #ifndef YALPS_DSHARD_RB16
+#define YALPS_DSHARD_RB16 4
+#endif
+    constexpr int JH = J > 8 ? 8 : J, RB = J > 8 ? YALPS_DSHARD_RB16 : 3; // (a chunk of a pending row is read once per RB half-rows: L2 reads, not HBM, bound the sweep)
     auto apply_batch = [&](int u0, double2 (&xb)[RB][JH], const int (&ri)[RB], int cnt) __attribute__((always_inline)) {
 #pragma unroll 1
         for (int p = 0; p < npend; p++) {

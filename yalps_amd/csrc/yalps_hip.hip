@@ -1738,7 +1738,9 @@ int32_t yalps_tableau_set_shard(yalps_tableau *t, int32_t rank, int32_t nranks, 
         for (int cand : {1, 2, 4, 6, 8, 16})
             if (!dJ && 512 * cand >= units) dJ = cand;
         if (t->wfn_inplace && dJ && env_int("YALPS_HIP_SHARD_DELAY", 1) && rows_per_block >= env_int("YALPS_HIP_DELAY_MIN_ROWS", 4)) {
-            const int depth = std::min(8, std::max(2, env_int("YALPS_HIP_DELAY_DEPTH", std::max(4, (rows_per_block + 1) / 3))));
+            // (measured, us per pivot at depth 2 / 4 / 6 / 8: 2049 x 16385 73 / 53 / 48 / 46, 8193 x 16385 207 / 125 / 105 / 97:
+            // a launch-per-pivot step has a larger fixed part than stream3_kernel's, the deepest form wins everywhere)
+            const int depth = std::min(8, std::max(2, env_int("YALPS_HIP_DELAY_DEPTH", 8)));
             const bool nt = env_int("YALPS_HIP_SHARD_NT", sizeof(double) * (size_t)d.pitch * (size_t)t->height > SWEEP_BEYOND_CACHE ? 1 : 0) != 0;
             const size_t lds = sizeof(double) * (2 * (size_t)depth + 2) * (size_t)rows_per_block + sizeof(int32_t) * (size_t)rows_per_block;
             if (lds <= 150 * 1024)
