@@ -23,14 +23,17 @@ python3 tools/netlib_paths.py > $out/netlib_paths.txt 2>&1
 YALPS_HIP_DELAY=0 python3 tools/netlib_paths.py > $out/netlib_paths_nodelay.txt 2>&1
 python3 bench_bnb.py > $out/bnb.json 2> $out/bnb.err
 python3 bench_table.py > $out/table.json 2> $out/table.err
-python3 bench.py --workload sharded --size 16384 --gpus 1 --steps 2 --warmup 1 2> $out/shard16384.err | grep "^{" > $out/shard16384.json
-python3 bench.py --workload sharded --size 4096 --gpus 1 --steps 2 --warmup 1 2>/dev/null | grep "^{" > $out/shard4096.json
-rocprofv3 --kernel-trace --stats -d $out/shstats --output-format csv -- python3 bench.py --workload sharded --size 16384 --gpus 1 --steps 1 --warmup 1 > /dev/null 2>&1
+# row shards: one sweep per pivot (wide_kernel in place; what profiles/r02_sharded_16384* hold) ...
+YALPS_HIP_SHARD_DELAY=0 python3 bench.py --workload sharded --size 16384 --gpus 1 --steps 2 --warmup 1 2> $out/shard16384.err | grep "^{" > $out/shard16384.json
+YALPS_HIP_SHARD_DELAY=0 python3 bench.py --workload sharded --size 4096 --gpus 1 --steps 2 --warmup 1 2>/dev/null | grep "^{" > $out/shard4096.json
+YALPS_HIP_SHARD_DELAY=0 rocprofv3 --kernel-trace --stats -d $out/shstats --output-format csv -- python3 bench.py --workload sharded --size 16384 --gpus 1 --steps 1 --warmup 1 > /dev/null 2>&1
 find $out/shstats -name "*kernel_stats.csv" -exec cp {} $out/shard16384_kernel_stats.csv \; ; rm -rf $out/shstats
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c -d $out/shpmc_$c --output-format csv -- python3 bench.py --workload sharded --size 16384 --gpus 1 --steps 1 --warmup 1 > /dev/null 2>&1
+  YALPS_HIP_SHARD_DELAY=0 rocprofv3 --pmc $c -d $out/shpmc_$c --output-format csv -- python3 bench.py --workload sharded --size 16384 --gpus 1 --steps 1 --warmup 1 > /dev/null 2>&1
   python3 tools/pmc_summary.py $out/shpmc_$c $c wide_kernel > $out/shard16384_$c.json; rm -rf $out/shpmc_$c
 done
+# ... and with delayed row updates (dshard_kernel, the default): profiles/r02_shard_delay_*
+tools/shard_measurements.sh $out/shard_delay
 # sweep_kernel on the HBM-bound shapes: rocprof kernel stats + PMC passes of one bounded launch each
 for shape in "16384 0 300" "8192 0 800" "16384 1024 2000" "16384 4096 600"; do
   set -- $shape; tag=$( [ "$2" = 0 ] && echo $(( $1 + 1 ))x$(( $1 + 1 )) || echo $(( $2 + 1 ))x$(( $1 + 1 )) )
