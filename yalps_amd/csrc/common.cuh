@@ -51,6 +51,7 @@ struct alignas(16) DelayState {
     int32_t pad_[2];
     int32_t pl[8]; // per pending pivot, oldest first: the pivot row as a LOCAL row of this rank (-1: another rank's)
     int32_t pc[8]; // ... its pivot column (mat index)
+    int32_t fast[8]; // ... bit w: wave w's slice of its normalised row holds no FLUSHED mark (:31's select-free path; the same in every workgroup)
 };
 
 struct alignas(16) Part {

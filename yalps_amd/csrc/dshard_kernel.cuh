@@ -26,8 +26,12 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
     __shared__ int sh_nt;
     constexpr int MAXD = 8;
     __shared__ int sh_pl[MAXD], sh_pc[MAXD]; // the pending pivots, oldest first: my slot of the pivot row (-1: not mine), pivot column (mat index)
+    __shared__ int sh_fast[MAXD][T / 64];    // per wave: nothing of its slice of that pivot row was flushed (:31 select-free path)
     constexpr int JC = J > 8 ? 8 : J;        // units per lane that pass through registers at a time (a pivot row being decided)
-    constexpr int JA = J > 8 ? 8 : J;        // ... of a pending pivot row while it is applied to the rows in flight
+#ifndef YALPS_DSHARD_JA16
+#define YALPS_DSHARD_JA16 8
+#endif
+    constexpr int JA = J > 8 ? YALPS_DSHARD_JA16 : J; // ... of a pending pivot row while it is applied to the rows in flight
     extern __shared__ __attribute__((aligned(16))) double sm_dyn[]; // colv[depth][rpw], nqv[depth][rpw], lav[rpw], rhsv[rpw], tlist[rpw] (int)
 
     const int tid = threadIdx.x, NB = d.nb, b = blockIdx.x;
@@ -90,7 +94,16 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
         const int lr = tid < npend ? Din->pl[tid] : -1;
         sh_pl[tid] = (lr >= 0 && lr % NB == b) ? lr / NB : -1;
         sh_pc[tid] = tid < npend ? Din->pc[tid] : 0;
+        const int fm = tid < npend ? Din->fast[tid] : 0;
+        for (int wv = 0; wv < T / 64; wv++) sh_fast[tid][wv] = (fm >> wv) & 1;
     }
+    unsigned padmask = 0; // columns of mine that do not exist (c0 + k >= n): 0.0 in a pivot row, must not count as "flushed"
+#pragma unroll
+    for (int j = 0; j < J; j++)
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+            if (2 * (tid + j * T) + k >= n) padmask |= 1u << (2 * j + k);
+    constexpr unsigned FULL = J == 16 ? 0xFFFFFFFFu : (1u << (2 * (J & 15))) - 1u;
     for (int i = tid; i < my_rows; i += T) {
         const int r = b + NB * i;
         for (int p = 0; p < npend; p++) {
@@ -144,6 +157,11 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
         for (int p = 0; p < npend; p++) {
             const __amdgpu_buffer_rsrc_t rsp = rsrc_of(prow0 + (size_t)p * pitch);
             const int colxp = sh_pc[p], lslotp = sh_pl[p];
+            const bool fastp = sh_fast[p][tid >> 6] != 0;
+            // the one element of a row that the pivot column replaces (:25, :36): unit `up` of lane `lp` -- the unit is the same
+            // for every lane, so all but one of the unrolled units skip the patch on a scalar compare
+            const int up = (colxp >> 1) / T;
+            const bool lane_p = ((colxp >> 1) % T) == tid;
             double coefu[RB], patchu[RB];
             bool pivu[RB], actu[RB];
 #pragma unroll
@@ -163,24 +181,31 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
                     if (!actu[u]) continue; // (uniform)
 #pragma unroll
                     for (int j = 0; j < JA; j++) {
-                        const int c0 = 2 * (tid + (u0 + jb + j) * T);
                         double2 &xv = xb[u][jb + j];
-                        const bool f0 = (unsigned long long)__double_as_longlong(pn[j].x) != FLUSHED;
-                        const bool f1 = (unsigned long long)__double_as_longlong(pn[j].y) != FLUSHED;
-                        if (pivu[u]) {
-                            xv.x = f0 ? pn[j].x : 0.0;
-                            xv.y = f1 ? pn[j].y : 0.0;
-                        } else {
+                        if (fastp && !pivu[u]) {
                             const double px = coefu[u] * pn[j].x, py = coefu[u] * pn[j].y;
-                            const double nx = xv.x - px, ny = xv.y - py;
-                            xv.x = f0 ? nx : xv.x;
-                            xv.y = f1 ? ny : xv.y;
+                            xv.x = xv.x - px;
+                            xv.y = xv.y - py;
+                        } else {
+                            const bool f0 = (unsigned long long)__double_as_longlong(pn[j].x) != FLUSHED;
+                            const bool f1 = (unsigned long long)__double_as_longlong(pn[j].y) != FLUSHED;
+                            if (pivu[u]) {
+                                xv.x = f0 ? pn[j].x : 0.0;
+                                xv.y = f1 ? pn[j].y : 0.0;
+                            } else {
+                                const double px = coefu[u] * pn[j].x, py = coefu[u] * pn[j].y;
+                                const double nx = xv.x - px, ny = xv.y - py;
+                                xv.x = f0 ? nx : xv.x;
+                                xv.y = f1 ? ny : xv.y;
+                            }
                         }
-                        if (c0 == (colxp & ~1)) {
-                            if (colxp & 1)
-                                xv.y = patchu[u];
-                            else
-                                xv.x = patchu[u];
+                        if (up == u0 + jb + j) { // (uniform)
+                            if (lane_p) {
+                                if (colxp & 1)
+                                    xv.y = patchu[u];
+                                else
+                                    xv.x = patchu[u];
+                            }
                         }
                     }
                 }
@@ -399,6 +424,7 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
     const double nq0 = -coef0 / q; // :36 for the objective row
     const __amdgpu_buffer_rsrc_t rsrc_src = rsrc_of(mrow), rsrc_new = rsrc_of(prow0 + (size_t)npend * pitch), rs_objB = rsrc_of(objB);
     KI best = {INFINITY, INT_MAX};
+    unsigned nzmask = 0;
 #pragma unroll 1
     for (int jb = 0; jb < J; jb += JC) {
         double2 pv[JC], ob[JC];
@@ -417,6 +443,7 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
                 const bool nzk = fabs(v) > 1e-16;
                 const double vn = nzk ? v / q : 0.0;
                 pn = with_elem(pn, k, nzk ? vn : flushed);
+                if (nzk) nzmask |= 1u << (2 * (jb + j) + k);
                 double o1 = elem(ov, k);
                 if (touched0) {
                     if (c0 + k == colx)
@@ -435,6 +462,10 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
             if (b == 0) row_st16<AUX_PLAIN>(rs_objB, lane_off + 16 * T * (jb + j), 0, ov);
             row_st16<AUX_PLAIN>(rsrc_new, lane_off + 16 * T * (jb + j), 0, pn);
         }
+    }
+    {
+        const bool fast = __builtin_amdgcn_ballot_w64(((nzmask | padmask) & FULL) != FULL) == 0; // (per wave)
+        if ((tid & 63) == 0) sh_fast[npend][tid >> 6] = fast ? 1 : 0;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (my stores of the pending row are out before the barrier below: the scalar chains read them at L2)
     if (tid == 0) {
@@ -500,6 +531,9 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
         for (int p = 0; p < MAXD; p++) {
             o.pl[p] = p < npend_out ? (p == npend - 1 ? lrow : Din->pl[p]) : -1;
             o.pc[p] = p < npend_out ? (p == npend - 1 ? colx : Din->pc[p]) : 0;
+            int fm = 0;
+            for (int wv = 0; wv < T / 64; wv++) fm |= (sh_fast[p][wv] != 0 ? 1 : 0) << wv;
+            o.fast[p] = p < npend_out ? fm : 0;
         }
         *Dout = o;
     }
