@@ -85,6 +85,7 @@ struct Desc {
     unsigned long long *rc_flag[2]; // [nb][2] {candidate key bits, (epoch << 32) | global row index}
     int32_t *rc_err;                // set when a workgroup gives up waiting (never expected)
     unsigned long long *rc_verdict; // [2] checkCycles: workgroup 0's verdict on the pivot of an epoch, (epoch << 32) | cycled
+    unsigned long long *rc_rowflag; // [2][2] stream3_kernel's two-step exchange: {RHS entry of the winner's row, (epoch << 32) | row}, by epoch parity
     int32_t perm_len;
     int32_t extra;  // resident_kernel<.., true>: rows per workgroup parked in LDS (0: none)
     int32_t xl_ofs; // ... and where they start in the dynamic LDS block, in int32 units (behind var[] / pos[] at capacity)

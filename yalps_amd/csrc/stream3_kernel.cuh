@@ -21,7 +21,16 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
     __shared__ int si[2][16];
     __shared__ double sh_q, sh_c0; // quotient; objective-row entry of the pivot column
     __shared__ int sh_fail, sh_nt, sh_flag, sh_verdict;
+    __shared__ double sh_rowrhs;
     constexpr int MAXD = 8;
+    // TWO: the exchange in two steps -- every workgroup publishes its candidate's KEY only; the workgroup that owns the winner
+    // then publishes that one row (pending pivots applied) behind a second record.  One more hand-off on the pivot's chain,
+    // but 1 row instead of 256 goes through the pending pivots and the L2s per pivot (at 16 units per lane that was 335 MB of
+    // L2 traffic per pivot).  Rows of 4098+ columns; narrower ones keep the single hand-off.
+#ifndef YALPS_S3_TWO_MIN_J
+#define YALPS_S3_TWO_MIN_J 8
+#endif
+    constexpr bool TWO = J >= YALPS_S3_TWO_MIN_J && !CHECK; // (with hasCycle the 16-unit form does not fit the registers)
     __shared__ int sh_pl[MAXD], sh_pc[MAXD]; // the pending pivots, oldest first: my slot of the pivot row (-1: not mine), pivot column (mat index)
     __shared__ int sh_fast[MAXD][T / 64];       // per wave: nothing of its slice of that pivot row was flushed (:31 select-free path)
     constexpr int JC = J > 8 ? 8 : J; // units per lane that pass through registers at a time (a pivot row being decided)
@@ -290,10 +299,8 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
         return c;
     };
     unsigned epoch = 0;
-    // my candidate and its row AS IT IS NOW (memory + pending pivots, in registers; not stored): write-through, drained, flag
-    auto publish = [&](KI cand) __attribute__((always_inline)) {
-        epoch++;
-        const int par = epoch & 1, cg = cand.i == INT_MAX ? 0 : cand.i / NB;
+    // a row of mine AS IT IS NOW (memory + pending pivots, in registers; not stored in place) -> my slot of the hand-off rows: write-through, drained
+    auto publish_row = [&](int par, int cg) __attribute__((always_inline)) {
         if (my_rows > 0) {
             const __amdgpu_buffer_rsrc_t rsm = rsrc_of(mat + (size_t)(b + NB * cg) * pitch), rsd = rsrc_of(d.rc_rows[par] + (size_t)b * pitch);
     #pragma unroll 1
@@ -309,9 +316,17 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
                 for (int j = 0; j < JH; j++) row_st16<AUX_SC1>(rsd, lane_off + 16 * T * (u0 + j), 0, xb[0][j]);
             }
         }
-        if (tid == 0) st_sc1(d.rc_key[par] + b, rhsv[cg]); // the candidate row's RHS entry
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains ...
-        __syncthreads();                                    // ... before ONE lane raises the flag:
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains ...
+        __syncthreads();                                  // ... before ONE lane raises the flag
+    };
+    // my candidate: (single hand-off) with its row; (TWO) its key only
+    auto publish = [&](KI cand) __attribute__((always_inline)) {
+        epoch++;
+        const int par = epoch & 1, cg = cand.i == INT_MAX ? 0 : cand.i / NB;
+        if constexpr (!TWO) {
+            if (tid == 0) st_sc1(d.rc_key[par] + b, rhsv[cg]); // the candidate row's RHS entry
+            publish_row(par, cg);
+        }
         if (tid == 0) // ONE 16-byte record {candidate key, epoch << 32 | row}, one store, polled with one 16-byte load
             st16_sc1(reinterpret_cast<double *>(d.rc_flag[par] + 2 * b),
                      make_double2(cand.k, __longlong_as_double((long long)(((unsigned long long)epoch << 32) | (unsigned)cand.i))));
@@ -391,7 +406,38 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
         const int lslot = owner == b ? row / NB : -1; // my slot of the pivot row, if I own it
         // ---------------- the winner's row as published: the tableau's row after every earlier pivot ----------------
         const double *src = d.rc_rows[par] + (size_t)owner * pitch;
-        const double rhs_row = ld_sc1(d.rc_key[par] + owner);
+        double rhs_row;
+        if constexpr (TWO) { // the winner's owner publishes the row now; everybody waits for its record {RHS entry, epoch << 32 | row}
+            if (owner == b) {
+                publish_row(par, row / NB);
+                if (tid == 0) {
+                    sh_rowrhs = rhsv[row / NB];
+                    st16_sc1(reinterpret_cast<double *>(d.rc_rowflag + 2 * par),
+                             make_double2(rhsv[row / NB], __longlong_as_double((long long)(((unsigned long long)epoch << 32) | (unsigned)row))));
+                }
+            } else if (tid == 0) {
+                unsigned spins = 0;
+                unsigned long long spin_t0 = 0;
+                for (;;) {
+                    const double2 rec = ld16_sc1_one(d.rc_rowflag + 2 * par);
+                    if ((unsigned)((unsigned long long)__double_as_longlong(rec.y) >> 32) == epoch) {
+                        sh_rowrhs = rec.x;
+                        break;
+                    }
+                    if (spin_expired(spins, spin_t0, d.rc_err)) {
+                        sh_fail = 1;
+                        __hip_atomic_store(d.rc_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            __syncthreads();
+            if (sh_fail) return;
+            rhs_row = sh_rowrhs;
+        } else {
+            rhs_row = ld_sc1(d.rc_key[par] + owner);
+        }
         const __amdgpu_buffer_rsrc_t rsrc_src = rsrc_of(src);
         int col = la;
         if (phase == 1) { // :123-134, JC units of the raw row per lane at a time

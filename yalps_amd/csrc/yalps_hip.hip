@@ -769,7 +769,7 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
         const size_t tag_row = 2 * (size_t)d.pitch + 2;
         const size_t tag_bytes = t->rvar_tag.fn ? sizeof(double) * 2 * (size_t)t->nb * tag_row : 0;
         const size_t sweep_bytes = t->sweep ? ((size_t)yalps_sweep_sync_bytes() + 15) / 16 * 16 + 32 * 2 * (size_t)t->nb : 0;
-        t->rc_sync_bytes = sizeof(unsigned long long) * (2 * nflag + 2) + tag_bytes + sweep_bytes + 16; // (a multiple of 16)
+        t->rc_sync_bytes = sizeof(unsigned long long) * (2 * nflag + 2) + tag_bytes + sweep_bytes + 32 + 16; // (a multiple of 16; 32: rc_rowflag)
         HIP_TRY(hipMalloc(&t->ctl_block, t->rc_sync_bytes + 2 * sizeof(YState) + sizeof(YConst)));
         HIP_TRY(hipMemsetAsync(t->ctl_block, 0, t->rc_sync_bytes + 2 * sizeof(YState) + sizeof(YConst), s));
         t->rc_sync = t->ctl_block;
@@ -788,6 +788,7 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
         }
         char *tail = static_cast<char *>(t->ctl_block) + t->rc_sync_bytes;
         d.rc_err = reinterpret_cast<int32_t *>(tail - 16);
+        d.rc_rowflag = reinterpret_cast<unsigned long long *>(tail - 48);
         d.st = reinterpret_cast<YState *>(tail);
         d.cst = reinterpret_cast<YConst *>(tail + 2 * sizeof(YState));
         HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&t->host_ctl), 16 + 2 * sizeof(YState) + sizeof(YConst), hipHostMallocDefault));
