@@ -205,21 +205,6 @@ def main():
                                    "per step (%d pivots on rank 0), one independent LP per GPU" % (M, N, h, w, npiv),
                        "pivots_per_step": npiv, "objective_cell": result},
         }
-        if info["kernel"].startswith("dshard_kernel"):
-            # delayed row updates: a rank's rows are streamed once per `depth` pivots (dshard_kernel.cuh), so the algorithmic
-            # bytes / time is no efficiency; the row traffic actually moved is 1/depth of it
-            depth = int(info["kernel"].rsplit("delay_depth:", 1)[1])
-            rf = out["roofline"]
-            rf["algorithmic_equiv"] = {"achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-                                       "frac_of_copy_rate": ach / HBM_COPY_GBPS,
-                                       "note": "16*h*w bytes per pivot (SURVEY 8d) / n_gpus / time: what one sweep per pivot would have to move; not an efficiency"}
-            moved = ach / depth
-            rf["achieved"], rf["frac"], rf["frac_of_copy_rate"], rf["delay_depth"] = moved, moved / HBM_PEAK_GBPS, moved / HBM_COPY_GBPS, depth
-            rf["note"] = ("per GPU, delayed row updates: every touched row of the shard is read and written once per %d pivots; achieved = "
-                          "algorithmic bytes / n_gpus / depth / wall time of yalps_shard_run (the row traffic actually moved); the per-pivot "
-                          "figure is kept as algorithmic_equiv" % depth)
-        rf_kernel = info["kernel"]
-        out["roofline"]["kernel"] = rf_kernel
         if rehearsal:
             out["rehearsal"] = "ranks share GPU 0 (fewer GPUs than ranks): control-flow check only"
         if world == 1:

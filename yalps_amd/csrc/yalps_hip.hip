@@ -722,7 +722,11 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
         if (want_kernel == 3 && sJ && rows_per_block >= env_int("YALPS_HIP_DELAY_MIN_ROWS", 4)) {
             // depth: a pivot's head grows with the pivots pending (the candidate row gets them all applied before it is
             // published), the sweep shrinks: measured best 8 at 65 and 33 rows per workgroup, 6-8 at 17, 4 at 5-9
-            const int depth3 = std::min(8, std::max(2, env_int("YALPS_HIP_DELAY_DEPTH", std::max(4, (rows_per_block + 1) / 3))));
+            // (with the two-step exchange of the 8- and 16-unit forms only the winner's row gets them applied: 2049 x 16385 at
+            // depth 4 / 6 / 8: 48.1 / 46.2 / 44.8 us per pivot, 4097 x 8193 40.6 / 36.7 / 35.1, 4097 x 16385 73.8 / 64.5 / 60.5,
+            // 1025 x 16385 31.6 / 31.4 / 32.3)
+            const int depth_default = sJ >= 8 ? (rows_per_block >= 8 ? 8 : 6) : std::max(4, (rows_per_block + 1) / 3);
+            const int depth3 = std::min(8, std::max(2, env_int("YALPS_HIP_DELAY_DEPTH", depth_default)));
             const size_t lds3 = sizeof(double) * (2 * 512 * (size_t)sJ + (2 * (size_t)depth3 + 2) * (size_t)rows_per_block) + sizeof(int32_t) * (size_t)rows_per_block;
             if (lds3 <= 150 * 1024)
                 for (const RVariant &v : kStream3)
