@@ -26,9 +26,10 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
     // TWO: the exchange in two steps -- every workgroup publishes its candidate's KEY only; the workgroup that owns the winner
     // then publishes that one row (pending pivots applied) behind a second record.  One more hand-off on the pivot's chain,
     // but 1 row instead of 256 goes through the pending pivots and the L2s per pivot (at 16 units per lane that was 335 MB of
-    // L2 traffic per pivot).  Rows of 4098+ columns; narrower ones keep the single hand-off.
+    // L2 traffic per pivot).  Rows of 6 units per lane and more (4098+ columns; 5001^2 27.0 -> 25.7 us per pivot, 16385^2 167 -> 160);
+    // at 4 units (4097^2) it changes nothing measurable: the single hand-off stays there.
 #ifndef YALPS_S3_TWO_MIN_J
-#define YALPS_S3_TWO_MIN_J 8
+#define YALPS_S3_TWO_MIN_J 6
 #endif
     constexpr bool TWO = J >= YALPS_S3_TWO_MIN_J && !CHECK; // (with hasCycle the 16-unit form does not fit the registers)
     __shared__ int sh_pl[MAXD], sh_pc[MAXD]; // the pending pivots, oldest first: my slot of the pivot row (-1: not mine), pivot column (mat index)
