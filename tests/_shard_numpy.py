@@ -158,3 +158,178 @@ class NumpyShardOps:
 
     def close(self):
         pass
+
+
+class NumpyDelayedShardOps(NumpyShardOps):
+    """The same protocol with the DELAYED ROW UPDATES of dshard_kernel / dshard_select_kernel: a pivot stays
+    pending on this rank's rows (its normalised row, my rows' entries of its column as they were, what replaces them), the RHS
+    column and the objective row are updated at once, candidates come from scalar chains, the candidate rows are sent with
+    the pending pivots applied, and every `depth` pivots -- and when the solve ends -- all pending eliminations are carried
+    out in order.  Slot layout and collective unchanged: a rank with delayed updates and one without produce the same bytes."""
+
+    def __init__(self, *a, depth=4):
+        super().__init__(*a)
+        self.depth = depth
+
+    def begin(self, precision, max_pivots):
+        self.rhs = self.m[:, 0].copy()  # current
+        self.obj = self.m[0].copy()     # current (columns 1..)
+        self.pend = []
+        super().begin(precision, max_pivots)
+
+    def _column_now(self, c):
+        v = self.m[:, c].copy()
+        for (prow, pcol, pn, nz, colv, nq) in self.pend:
+            act = np.abs(colv) > 1e-16
+            if prow >= 0:
+                act[prow] = False
+            if c == pcol:
+                v[act] = nq[act]
+            elif nz[c]:
+                v[act] = v[act] - colv[act] * pn[c]
+            if prow >= 0:
+                v[prow] = nq[prow] if c == pcol else (pn[c] if nz[c] else 0.0)
+        return v
+
+    def _apply_to_row(self, x, i, p):
+        prow, pcol, pn, nz, colv, nq = p
+        if i == prow:
+            x[1:] = np.where(nz[1:], pn[1:], 0.0)
+            x[pcol] = nq[i]
+        elif abs(colv[i]) > 1e-16:
+            nzi = np.flatnonzero(nz[1:]) + 1
+            x[nzi] = x[nzi] - colv[i] * pn[nzi]
+            x[pcol] = nq[i]
+
+    def _row_now(self, i):
+        x = self.m[i].copy()
+        for p in self.pend:
+            self._apply_to_row(x, i, p)
+        return x
+
+    def _flush(self):
+        for p in self.pend:
+            for i in range(self.h):
+                self._apply_to_row(self.m[i], i, p)
+        if self.pend:
+            assert np.array_equal(self.m[0, 1:].view(np.int64), self.obj[1:].view(np.int64))
+        self.pend = []
+
+    def _finish(self):
+        self._flush()
+        self.m[:, 0] = self.rhs
+
+    def _scan(self):
+        p = self.precision
+        obj = self.obj[1:]
+        cand = np.where(obj > p)[0]
+        self.la = int(cand[np.argmax(obj[cand])]) + 1 if cand.size else 0
+        self.lav = self._column_now(self.la) if self.la else None
+        self.c_ratio, self.c_rhs = (INF, NONE), (INF, NONE)
+        for r in range(1, self.h):
+            g = r + self.base
+            rhs = self.rhs[r]
+            if rhs < -p and _better(rhs, g, *self.c_rhs):
+                self.c_rhs = (rhs, g)
+            if self.la:
+                v = self.lav[r]
+                if v > p:
+                    ratio = rhs / v
+                    if ratio < INF:
+                        key = -INF if ratio <= p else ratio
+                        if _better(key, g, *self.c_ratio):
+                            self.c_ratio = (key, g)
+
+    def select(self):
+        s = self.send.numpy()
+        s[:] = 0.0
+        (kr, ir), (kn, inn) = self.c_ratio, self.c_rhs
+        s[0:4] = (kr, float(ir), kn, float(inn))
+        n = self.w - 1
+        if self.status < 0:
+            if ir != NONE:
+                s[4] = self.rhs[ir - self.base]
+                s[HDR:HDR + n] = self._row_now(ir - self.base)[1:]
+            if inn != NONE:
+                s[5] = self.rhs[inn - self.base]
+                s[HDR + self.pitch:HDR + self.pitch + n] = self._row_now(inn - self.base)[1:]
+
+    def apply(self):
+        if self.status >= 0:
+            return
+        R = self.recv.numpy().reshape(self.nranks, self.slot)
+        p, n = self.precision, self.w - 1
+
+        def stop(status, result):
+            self.status, self.result = status, result
+            self._finish()
+
+        while True:
+            if not (self.iter < self.max_pivots):
+                return stop(3, math.nan)
+            if self.phase == 1:
+                best = (INF, NONE)
+                for g in range(self.nranks):
+                    if _better(R[g, 2], int(R[g, 3]), *best):
+                        best = (R[g, 2], int(R[g, 3]))
+                if best[1] == NONE:
+                    self.phase, self.iter = 2, 0.0
+                    continue
+                row = best[1]
+                slot = R[self._owner(row)]
+                prow, rhs_row = slot[HDR + self.pitch:HDR + self.pitch + n].copy(), slot[5]
+                col, mx = 0, -INF
+                for c in range(1, self.w):
+                    coefficient = prow[c - 1]
+                    if coefficient < -p:
+                        ratio = -self.obj[c] / coefficient
+                        if ratio > mx:
+                            mx, col = ratio, c
+                if col == 0:
+                    return stop(1, math.nan)
+                colv = self._column_now(col)
+                break
+            col = self.la
+            if col == 0:
+                return stop(0, _round_to_precision(self.rhs[0], p))
+            best = (INF, NONE)
+            for g in range(self.nranks):
+                if _better(R[g, 0], int(R[g, 1]), *best):
+                    best = (R[g, 0], int(R[g, 1]))
+            if best[1] == NONE:
+                return stop(2, float(col))
+            row = best[1]
+            slot = R[self._owner(row)]
+            prow, rhs_row = slot[HDR:HDR + n].copy(), slot[4]
+            colv = self.lav  # (the look-ahead priced exactly this column)
+            break
+        full = np.concatenate(([0.0], prow))  # (column 0, the RHS, is handled on its own below)
+        q = full[col]
+        leaving, entering = self.var[self.w + row], self.var[col]
+        self.var[self.w + row], self.var[col] = entering, leaving
+        self.pos[leaving], self.pos[entering] = col, self.w + row
+        nz = np.abs(full) > 1e-16
+        pn = np.where(nz, full / q, 0.0)
+        lrow = row - self.base if self.bounds[self.rank] <= row < self.bounds[self.rank + 1] else -1
+        nq = -colv / q
+        act = np.abs(colv) > 1e-16
+        if lrow >= 0:
+            nq[lrow] = 1.0 / q
+            act[lrow] = False
+        if abs(rhs_row) > 1e-16:
+            pn_rhs = rhs_row / q
+            self.rhs[act] = self.rhs[act] - colv[act] * pn_rhs
+            if lrow >= 0:
+                self.rhs[lrow] = pn_rhs
+        elif lrow >= 0:
+            self.rhs[lrow] = 0.0
+        if act[0]:
+            nzi = np.flatnonzero(nz)
+            self.obj[nzi] = self.obj[nzi] - colv[0] * pn[nzi]
+            self.obj[col] = nq[0]
+        self.pend.append((lrow, col, pn, nz, colv.copy(), nq))
+        self.iter += 1.0
+        self.pivots += 1
+        if len(self.pend) == self.depth:
+            self._flush()
+        self._scan()

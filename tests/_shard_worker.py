@@ -1,5 +1,5 @@
 """Worker of the multi-process row-sharded tests: one rank of a gloo (or nccl) group.
-usage: python -m tests._shard_worker <numpy|hip|hip-native> <M> <N> <seed> <out.npz> [max_pivots [digest|phase1]]
+usage: python -m tests._shard_worker <numpy|numpy-delayed<depth>|hip|hip-native> <M> <N> <seed> <out.npz> [max_pivots [digest|phase1]]
 (hip-native: the library's own loop, yalps_shard_run, with the host transport carried by gloo)
 (RANK/WORLD_SIZE/MASTER_* in env).  `digest`: instead of the assembled tableau, rank 0 saves the SHA-256 of the
 objective row and of every rank's block of rows (full-size runs: the tableau is 2.1 GB).  `phase1`: the input of
@@ -39,6 +39,9 @@ def main():
     if kind == "numpy":
         from tests._shard_numpy import NumpyShardOps
         ops = NumpyShardOps(local, w, bounds, rank, h, ident, ident.copy())
+    elif kind.startswith("numpy-delayed"):  # "numpy-delayed<depth>": the delayed row updates of dshard_kernel, on the CPU
+        from tests._shard_numpy import NumpyDelayedShardOps
+        ops = NumpyDelayedShardOps(local, w, bounds, rank, h, ident, ident.copy(), depth=int(kind[len("numpy-delayed"):] or 4))
     else:
         ops = sharded.HipShardOps(local, w, bounds, rank, h, ident, ident.copy(), device=0, private_stream=kind == "hip-native")
     del m
@@ -50,7 +53,7 @@ def main():
     else:
         comm = sharded.TorchComm()
         status, result, pivots = sharded.sharded_simplex(ops, comm, max_pivots=max_pivots, check_every=8 if max_pivots > 8 else 1)
-    kernel = "numpy" if kind == "numpy" else ops.tab.info()["streaming"]
+    kernel = kind if kind.startswith("numpy") else ops.tab.info()["streaming"]
     lm, pos, var = ops.download()
     if digest:
         import hashlib

@@ -65,6 +65,18 @@ def test_sharded_driver_gloo_cpu(oracle, tmp_path, world, M, N, seed):
     check_against_oracle(oracle, res, M, N, seed)
 
 
+@pytest.mark.parametrize("world,M,N,seed,depth,budget,phase1", [(2, 40, 30, 4, 3, None, False), (2, 37, 50, 5, 8, None, False),
+                                                                (3, 25, 25, 7, 2, None, False), (2, 30, 60, 9, 4, 33, True),
+                                                                (3, 45, 45, 10, 5, 50, True)])
+def test_sharded_delayed_protocol_gloo_cpu(oracle, tmp_path, world, M, N, seed, depth, budget, phase1):
+    """The delayed row updates of the row shards (dshard_kernel / dshard_select_kernel) as a numpy stand-in over gloo, world
+    sizes 2 and 3: candidates from scalar chains, candidate rows sent with the pending pivots applied, the sweep every `depth`
+    pivots and on the way out -- bit for bit the single-process oracle (the GPU tests run the same cases' kernels)."""
+    extra = ["inf" if budget is None else budget] + (["phase1"] if phase1 else [])
+    res = run_world("numpy-delayed%d" % depth, world, M, N, seed, tmp_path, extra)
+    check_against_oracle(oracle, res, M, N, seed, max_pivots=np.inf if budget is None else float(budget), phase1=phase1)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,M,N,seed", [(1, 200, 150, 4), (2, 300, 280, 5), (2, 90, 700, 2), (3, 64, 64, 9),
                                             (2, 120, 3000, 6), (2, 100, 9000, 8)])
