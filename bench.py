@@ -15,6 +15,13 @@ copy of the tableau that is already resident in HBM.  value = pivots executed / 
          N ranks (yalps_amd/sharded.py: one RCCL all-gather of candidates + candidate rows per pivot);
          a step = --pivots-per-step pivots of that solve; strong scaling.
 
+  N > 1, default workload: after the replicas measurement every rank also starts a child process that joins a second
+         process group and runs `--workload sharded --size 16384` (BASELINE config 5: ONE 16385 x 16385 tableau,
+         rows sharded over the N GPUs); rank 0 adds that line's figures as "sharded_c5" to the same JSON line.  The
+         children are separate processes with a time limit, so that nothing that goes wrong there -- RCCL init, graph
+         capture, memory, a hang -- can change this run's return code or headline: it becomes "sharded_c5": {"error": ...}
+         (--no-sharded-c5 skips it).
+
 Extra objects on the JSON line (N == 1 / rank 0 only):
   roofline      the dominant (only) kernel of the timed region.  At 2049^2 the tableau fits on chip
                 and that is resident_kernel: ONE launch = up to 4096 complete pivots (selection,
@@ -121,6 +128,9 @@ def main():
     ap.add_argument("--shard-rows", type=int, default=0,
                     help="sharded workload: M of dense-LP(M,size,seed) instead of size (one rank's share of a larger world, "
                          "measured on one GPU: e.g. 2048 rows of 16384 columns = a rank of 8)")
+    ap.add_argument("--no-sharded-c5", action="store_true", help="N > 1, default workload: skip the row-sharded config-5 measurement")
+    ap.add_argument("--sharded-c5-size", type=int, default=16384, help="M = N of the row-sharded LP measured beside the replicas when N > 1")
+    ap.add_argument("--sharded-c5-timeout", type=float, default=420.0, help="seconds the children of that measurement get")
     args = ap.parse_args()
 
     import torch
@@ -271,6 +281,10 @@ def main():
     work.close()
     pristine.close()
     ctx.close()
+    if dist is not None and not args.no_sharded_c5:
+        c5 = sharded_c5_in_children(args, dist, rank, local_rank, world)
+        if out is not None:
+            out["sharded_c5"] = c5
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -278,19 +292,60 @@ def main():
         print(json.dumps(out))
 
 
+def sharded_c5_in_children(args, dist, rank, local_rank, world):
+    """BASELINE config 5 beside the replicas (N > 1): every rank starts `bench.py --workload sharded --size 16384` as a
+    child process; the children form a process group of their own (fresh port from rank 0) and run the row-sharded solve
+    over RCCL.  Returns rank 0's summary of the child's JSON line, or {"error": ...}; never raises."""
+    import socket
+    import subprocess
+    try:
+        box = [None]
+        if rank == 0:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                box[0] = sk.getsockname()[1]
+        dist.broadcast_object_list(box, src=0)
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(box[0]), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_USE_AGENT_STORE", "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE"):
+            env.pop(k, None)  # (the children rendezvous through MASTER_ADDR / MASTER_PORT, not through the parent's agent)
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--workload", "sharded", "--size", str(args.sharded_c5_size),
+               "--steps", str(max(1, min(args.steps, 10))), "--warmup", "1", "--pivots-per-step", str(args.pivots_per_step)]
+        t0 = time.perf_counter()
+        child = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        try:
+            so, se = child.communicate(timeout=args.sharded_c5_timeout)
+        except subprocess.TimeoutExpired:
+            child.kill()
+            so, se = child.communicate()
+            return {"error": "timed out after %.0f s" % args.sharded_c5_timeout, "stderr_tail": se[-600:]}
+        if child.returncode != 0:
+            return {"error": "child exited with %d" % child.returncode, "stderr_tail": se[-600:]}
+        if rank != 0:
+            return None
+        line = [ln for ln in so.splitlines() if ln.startswith("{")]
+        if not line:
+            return {"error": "no JSON line from the child", "stderr_tail": se[-600:]}
+        rec = json.loads(line[-1])
+        return {"value": rec["value"], "unit": rec["unit"], "us_per_pivot": rec["roofline"]["us_per_pivot"], "n_gpus": rec["n_gpus"],
+                "scaling": rec["scaling"], "workload": rec["config"]["workload"], "exchange": rec["config"]["exchange"],
+                "roofline": rec["roofline"], "rehearsal": rec.get("rehearsal"), "wall_s": time.perf_counter() - t0}
+    except Exception as e:  # noqa: BLE001 -- by contract nothing here may change the headline or the return code
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
 def bench_sharded(args, torch, dist, rank, local_rank, world):
-    """ONE tableau row-sharded over the ranks; every rank generates the LP and keeps its block.  The pivot loop is the
+    """ONE tableau row-sharded over the ranks; every rank generates its own block of rows.  The pivot loop is the
     library's (yalps_shard_run): select kernel, ncclAllGather (RCCL over xGMI) on the same stream, apply kernel, a batch
     of pivots per hipGraph replay -- Python is entered once per timed region."""
     from yalps_amd import _native, sharded
     N = args.size
     M = args.shard_rows if args.shard_rows > 0 else N
     w, h = N + 1, M + 1
-    m = _native.dense_lp(M, N, 42)
     bounds = sharded.partition(h, world)
     ident = np.arange(w + h, dtype=np.int32)
-    local = sharded.local_rows(m, w, h, bounds, rank)
-    del m
+    # only this rank's rows are generated: the objective row + rows bounds[rank] .. bounds[rank + 1] of the stream
+    local = np.concatenate([_native.dense_lp_rows(M, N, 42, 0, 1), _native.dense_lp_rows(M, N, 42, bounds[rank], bounds[rank + 1])])
     rehearsal = world > torch.cuda.device_count()  # (ranks share GPU 0: RCCL refuses; the host transport over gloo instead)
 
     def run(pivots):

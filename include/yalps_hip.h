@@ -144,6 +144,9 @@ int32_t yalps_tableau_info(const yalps_tableau *t, char *buf, int32_t len);
  * shader cycles [0..19], pivots [20], s_memtime span [21], s_memrealtime span [22]).  Returns the number of words
  * copied; the shipped library executes no stamp and returns YALPS_E_ARG. */
 int32_t yalps_tableau_debug_stamps(yalps_tableau *t, uint64_t *out, int32_t cap_words, int32_t reset);
+/* Diagnostic: device rows are padded to a multiple of 16 doubles; counts the padding doubles of the current buffer that
+ * are not finite / not zero (tests: a kernel that multiplied a padding lane by a marker would show here). */
+int32_t yalps_tableau_padding_check(yalps_tableau *t, int64_t *nonfinite_out, int64_t *nonzero_out);
 
 /* Run the two-phase simplex on the resident tableau (in place).  gpu_ms_out (optional) =
  * HIP-event time of the whole pivot loop on the context's stream. */
@@ -242,6 +245,9 @@ int32_t yalps_milp_f64(const double *matrix, int32_t width, int32_t height, cons
  * dense-LP(M,N,seed): fills a (M+1) x (N+1) row-major tableau with the
  * reference test-suite's PRNG stream (tests/helpers/util.ts:20-41).  Host-side, deterministic. */
 void yalps_dense_lp_f64(int32_t M, int32_t N, double seed, double *matrix);
+/* Rows [row_begin, row_end) of the same tableau (row 0 = objective row), row-major into `rows`: what one rank of a
+ * row-sharded solve holds -- the stream is walked through the rows before, nothing else is generated or stored. */
+void yalps_dense_lp_rows_f64(int32_t M, int32_t N, double seed, int32_t row_begin, int32_t row_end, double *rows);
 
 /* JS-exact roundToPrecision (src/util.ts:1-4), for host marshalling code. */
 double yalps_round_to_precision(double num, double precision);

@@ -321,9 +321,13 @@ static uint32_t yo_hash32(uint32_t x) {
 
 static double yo_rand(double *seed) {
     *seed += 2654435769.0; /* 0x9e3779b9, in double arithmetic */
-    /* JS ToInt32: the integer value modulo 2^32 */
-    double s = fmod(*seed, 4294967296.0);
-    uint32_t x = (uint32_t)(uint64_t)s;
+    /* JS ToInt32: the integer value modulo 2^32.  An integer-valued seed below 2^63 converts exactly to uint64_t and
+     * the truncation to 32 bits IS the modulo (fmod, 50 x slower, only for anything else). */
+    uint32_t x;
+    if (*seed >= 0.0 && *seed < 9223372036854775808.0 && *seed == (double)(uint64_t)*seed)
+        x = (uint32_t)(uint64_t)*seed;
+    else
+        x = (uint32_t)(uint64_t)fmod(*seed, 4294967296.0);
     return (double)yo_hash32(x) / 4294967296.0;
 }
 

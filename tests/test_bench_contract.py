@@ -44,3 +44,41 @@ def test_sharded_workload_line(extra, kernel):
     assert rec["roofline"]["kernel"].startswith(kernel), rec["roofline"]
     if kernel == "dshard_kernel":
         assert rec["roofline"]["delay_depth"] == 8 and "algorithmic_equiv" in rec["roofline"]
+
+
+def _bench_ranks(n, args):
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", str(n)] + args, cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_two_ranks_line_carries_the_row_sharded_measurement():
+    """The driver's multi-GPU command, rehearsed with two ranks sharing the test GPU: the replicas headline, and beside it
+    `sharded_c5` -- ONE tableau row-sharded over the ranks, measured by child processes in a group of their own (here a
+    4097 x 4097 stand-in for config 5 over the host transport; on a node: 16385 x 16385 over RCCL)."""
+    rec = _bench_ranks(2, ["--size", "300", "--steps", "2", "--warmup", "1", "--sharded-c5-size", "4096", "--pivots-per-step", "40"])
+    for k in KEYS[:-1]:
+        assert k in rec, k
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
+    c5 = rec["sharded_c5"]
+    assert "error" not in c5, c5
+    assert c5["n_gpus"] == 2 and c5["scaling"] == "strong" and c5["value"] > 0 and c5["us_per_pivot"] > 0
+    assert c5["roofline"]["kernel"].startswith("dshard_kernel") and c5["exchange"]["transport"] == "host"
+    assert "4097x4097" in c5["workload"]
+
+
+@pytest.mark.gpu
+def test_a_failing_row_sharded_measurement_leaves_the_headline_alone():
+    """Children that do not finish in time are killed and reported; the line, its headline and the return code stay."""
+    rec = _bench_ranks(2, ["--size", "300", "--steps", "2", "--warmup", "1", "--sharded-c5-size", "4096", "--sharded-c5-timeout", "0.05"])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and "timed out" in rec["sharded_c5"]["error"]

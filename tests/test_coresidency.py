@@ -118,3 +118,54 @@ def test_batch_solve_rejects_bad_cut_lists():
     finally:
         b.close()
         ctx.close()
+
+
+def test_lock_wait_is_bounded_and_the_lock_file_is_not_a_trap(tmp_path):
+    """(a) the per-device lock is taken with LOCK_NB and a deadline -- while a stranger holds the file, a solve
+    falls back to the launch-per-pivot kernels (bit-exact), says so and counts a give-up instead of blocking for ever;
+    (b) a lock path that was pre-planted as a symbolic link is refused (O_NOFOLLOW, regular single-link file of this user),
+    the link's target is left alone, solves go on without the inter-process lock."""
+    import fcntl
+    lock_dir = tmp_path / "locks"
+    lock_dir.mkdir(mode=0o700)
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "from tests import _golden as G, _oracle\n"
+        "from yalps_amd import _native as n\n"
+        "rec = next(r for r in G.records('dense') if r['M'] == 256)\n"
+        "m = G.initial_matrix(rec, _oracle.load(), dense_gen=n.dense_lp); pos, var = G.identity_perms(rec)\n"
+        "exp = G.expected(rec)\n"
+        "ctx = n.Context(0); t = n.DeviceTableau(ctx, rec['width'], rec['height'])\n"
+        "t.upload(m, rec['height'], pos, var)\n"
+        "st, res, piv, _ = t.solve(max_pivots=float('inf')); info = t.info(); gm, gp, gv = t.download()\n"
+        "assert (st, res, piv) == (exp['status'], exp['result'], exp['n_pivots']), (st, res, piv)\n"
+        "assert G.sha256(gm) == exp['final_sha256'] and np.array_equal(gp, exp['pos'])\n"
+        "print('path', info['last_path'], 'giveups', info['giveups'], 'lock_giveups', info['lock_giveups'])\n" % ROOT)
+    env = dict(os.environ, YALPS_HIP_LOCK_DIR=str(lock_dir), YALPS_HIP_LOCK_WAIT_MS="150")
+
+    def run():
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        return out
+
+    out = run()  # creates the lock file; nobody holds it
+    assert "path resident giveups 0 lock_giveups 0" in out.stdout, out.stdout + out.stderr
+    files = list(lock_dir.iterdir())
+    assert len(files) == 1 and files[0].name.startswith("yalps_hip_") and (files[0].stat().st_mode & 0o777) == 0o600, files
+    with open(files[0], "r+") as held:  # (a) a stranger sits on the lock
+        fcntl.flock(held, fcntl.LOCK_EX)
+        t0 = time.perf_counter()
+        out = run()
+        assert time.perf_counter() - t0 < 120
+        fcntl.flock(held, fcntl.LOCK_UN)
+    assert "path streaming giveups 1 lock_giveups 1" in out.stdout, out.stdout + out.stderr
+    assert "did not get the device's lock file in time" in out.stderr, out.stderr
+    victim = tmp_path / "victim.txt"  # (b) the lock path is a link to a file of ours
+    victim.write_text("precious")
+    victim.chmod(0o600)
+    files[0].unlink()
+    files[0].symlink_to(victim)
+    out = run()
+    assert "cannot use" in out.stderr and "as a lock file" in out.stderr, out.stderr
+    assert "path resident giveups 0 lock_giveups 0" in out.stdout, out.stdout + out.stderr
+    assert victim.read_text() == "precious" and (victim.stat().st_mode & 0o777) == 0o600

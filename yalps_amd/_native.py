@@ -19,11 +19,11 @@ SYMBOLS = (
     "yalps_last_error", "yalps_device_count", "yalps_simplex_f64", "yalps_simplex_f64_ex", "yalps_ctx_create",
     "yalps_ctx_destroy", "yalps_tableau_create", "yalps_tableau_destroy", "yalps_tableau_upload",
     "yalps_tableau_download", "yalps_tableau_download_rhs", "yalps_tableau_copy", "yalps_tableau_height",
-    "yalps_tableau_solve", "yalps_tableau_pivot", "yalps_tableau_bench_sweep", "yalps_dense_lp_f64",
+    "yalps_tableau_solve", "yalps_tableau_pivot", "yalps_tableau_bench_sweep", "yalps_dense_lp_f64", "yalps_dense_lp_rows_f64",
     "yalps_round_to_precision", "yalps_ctx_create_on_stream", "yalps_tableau_set_shard", "yalps_shard_slot_doubles",
     "yalps_shard_begin", "yalps_shard_select", "yalps_shard_apply", "yalps_shard_poll", "yalps_tableau_info",
     "yalps_tableau_assemble", "yalps_simplex_sparse_f64", "yalps_tableau_apply_cuts", "yalps_tableau_node_solve", "yalps_tableau_download_solution", "yalps_milp_f64", "yalps_batch_create", "yalps_batch_destroy", "yalps_batch_set_root", "yalps_batch_solve", "yalps_batch_download",
-    "yalps_tableau_debug_stamps", "yalps_comm_unique_id", "yalps_comm_create", "yalps_comm_create_host", "yalps_comm_destroy",
+    "yalps_tableau_debug_stamps", "yalps_tableau_padding_check", "yalps_comm_unique_id", "yalps_comm_create", "yalps_comm_create_host", "yalps_comm_destroy",
     "yalps_comm_info", "yalps_shard_run",
 )
 
@@ -138,6 +138,8 @@ def lib():
         L.yalps_tableau_bench_sweep.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float)]
         L.yalps_dense_lp_f64.restype = None
         L.yalps_dense_lp_f64.argtypes = [C.c_int32, C.c_int32, C.c_double, vp]
+        L.yalps_dense_lp_rows_f64.restype = None
+        L.yalps_dense_lp_rows_f64.argtypes = [C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_int32, vp]
         L.yalps_round_to_precision.restype = C.c_double
         L.yalps_round_to_precision.argtypes = [C.c_double, C.c_double]
         _lib = L
@@ -306,6 +308,12 @@ class DeviceTableau:
         n = check(lib().yalps_tableau_debug_stamps(self.handle, out.ctypes.data, out.size, int(bool(reset))))
         return out[:n].reshape(-1, 24)
 
+    def padding_check(self):
+        """(non-finite, non-zero) doubles in the row padding of the current device buffer (yalps_tableau_padding_check)."""
+        bad, nz = C.c_int64(), C.c_int64()
+        check(lib().yalps_tableau_padding_check(self.handle, C.byref(bad), C.byref(nz)))
+        return bad.value, nz.value
+
     def pivot(self, row, col):
         check(lib().yalps_tableau_pivot(self.handle, row, col))
 
@@ -448,6 +456,15 @@ def dense_lp(M, N, seed=42.0):
     """dense-LP(M,N,seed) of SURVEY.md 8(d) as a flat row-major (M+1)x(N+1) tableau."""
     m = np.zeros((M + 1) * (N + 1), np.float64)
     lib().yalps_dense_lp_f64(M, N, float(seed), m.ctypes.data)
+    return m
+
+
+def dense_lp_rows(M, N, seed, row_begin, row_end):
+    """Rows [row_begin, row_end) of dense-LP(M,N,seed) (row 0 = objective row), flat row-major: one rank's share of a
+    row-sharded tableau without the 8*(M+1)*(N+1) bytes of the whole."""
+    row_end = min(row_end, M + 1)
+    m = np.zeros(max(row_end - row_begin, 0) * (N + 1), np.float64)
+    lib().yalps_dense_lp_rows_f64(M, N, float(seed), row_begin, row_end, m.ctypes.data)
     return m
 
 

@@ -35,6 +35,12 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
     extern __shared__ __attribute__((aligned(16))) double sm_dyn[]; // colv[depth][rpw], nqv[depth][rpw], lav[rpw], rhsv[rpw], tlist[rpw] (int)
 
     const int tid = threadIdx.x, NB = d.nb, b = blockIdx.x;
+#ifdef YALPS_STAMPS
+    // diagnostic build: stage sums of this launch, added to d.dbg[b] on the way out (stages: tools/shard_stages.py)
+    unsigned long long st_acc[20] = {}, st_last = 0, st_t0 = 0, st_r0 = 0;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t0), "=s"(st_r0)::"memory");
+    st_last = st_t0;
+#endif
     const YState *Sin = d.st + parity;
     YState *Sout = d.st + (parity ^ 1);
     const DelayState *Din = d.dstate + parity;
@@ -114,6 +120,7 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
         lav[i] = lav_valid ? d.dlav[r] : 0.0;
     }
     __syncthreads();
+    YSTAMP(0); // state, the pending pivots' scalars of my rows -> LDS
 
     // entry (my row slot i, mat column c) after ONE pending pivot, given the entry before it (:14-25, :31-36 for one element)
     auto after1 = [&](double p, const double *colvp, const double *nqvp, int lslotp, int colxp, int i, double v, int c)
@@ -377,6 +384,7 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
             break;
         }
     }
+    YSTAMP(1); // decide (the gathered records, phase 1: the entering column)
     if (term != RUNNING) { // the solve ends here: the pending pivots are carried out on the way out
         flush_pending();
         if (b == 0 && tid == 0) {
@@ -401,6 +409,7 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
     } else {
         column_now(colx, colvN);
     }
+    YSTAMP(2); // my rows' entries of the pivot column
     const bool nz_rhs = fabs(rhs_row) > 1e-16;
     const double pn_rhs = nz_rhs ? rhs_row / q : 0.0;
     for (int i = tid; i < my_rows; i += T) { // RHS entries of my rows (:33 at column 0)
@@ -418,6 +427,7 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
         d.dcolv[(size_t)npend * hcap + r] = coef;
         d.dnqv[(size_t)npend * hcap + r] = nq;
     }
+    YSTAMP(3); // RHS, what replaces the pivot column; the pending scalars stored
     // one pass over the pivot row, JC units per lane at a time: normalised -> d.dpend[npend] (:14-25; FLUSHED marks what pivot()
     // zeroed), the objective replica of the next launch (:27-38 for row 0; workgroup 0 stores it), priced (:71-79) in registers
     const bool touched0 = fabs(coef0) > 1e-16;
@@ -463,11 +473,23 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
             row_st16<AUX_PLAIN>(rsrc_new, lane_off + 16 * T * (jb + j), 0, pn);
         }
     }
+    // The doubles behind column n of a device row are padding (rows are 128 bytes apart): the pass above has marked them
+    // FLUSHED like any other zero; the select-free path of the sweep multiplies every lane's units by this row, so the
+    // lane that holds them overwrites its own marks with a finite 0.0 (same lane, same address: in order).
+    {
+        const int u_first = n >> 1, d_lane = (tid - u_first) & (T - 1); // (T is a power of two)
+        if (d_lane < (pitch >> 1) - u_first) {
+            const int c0p = 2 * (u_first + d_lane);
+            if (c0p >= n) (prow0 + (size_t)npend * pitch)[c0p] = 0.0;
+            (prow0 + (size_t)npend * pitch)[c0p + 1] = 0.0;
+        }
+    }
     {
         const bool fast = __builtin_amdgcn_ballot_w64(((nzmask | padmask) & FULL) != FULL) == 0; // (per wave)
         if ((tid & 63) == 0) sh_fast[npend][tid >> 6] = fast ? 1 : 0;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (my stores of the pending row are out before the barrier below: the scalar chains read them at L2)
+    YSTAMP(4); // the pivot row: normalised + stored, objective replica, priced in registers
     if (tid == 0) {
         sh_pl[npend] = lslot;
         sh_pc[npend] = colx;
@@ -476,12 +498,14 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
     best = block_argmin<T>(best, sk, si, slot); // (its barrier also publishes the pending row / rhsv / the pending scalars to my waves)
     slot ^= 1;
     const int la = best.i == INT_MAX ? 0 : best.i;
+    YSTAMP(5); // arg-max of the pricing (barriers)
 
     // ---------------- my candidates for the next pivot: from scalars ----------------------------------------------------
     if (la > 0)
         column_now(la - 1, lav); // my rows' entries of column la after every pivot so far
     else
         __syncthreads();
+    YSTAMP(6); // my rows' entries of the next entering column (scalar chains)
     KI cand_ratio = {INFINITY, INT_MAX}, cand_rhs = {INFINITY, INT_MAX};
     for (int i = tid; i < my_rows; i += T) {
         const int r = b + NB * i;
@@ -521,6 +545,7 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
         p.idx = cand_rhs.i;
         d.part_rhs[pbuf ^ 1][b] = p;
     }
+    YSTAMP(7); // my candidates, two arg-mins, the partials
     // ---------------- the rows: only every depth-th pivot ------------------------------------------------------------------
     const int npend_out = npend == depth ? 0 : npend;
     if (b == 0 && tid == 0) {
@@ -537,7 +562,21 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
         }
         *Dout = o;
     }
+    YSTAMP(8); // state
     if (npend == depth) flush_pending();
+    YSTAMP(9); // the sweep (every depth-th launch)
+#ifdef YALPS_STAMPS
+    if (tid == 0 && d.dbg) {
+        unsigned long long t1, r1;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1)::"memory");
+        unsigned long long *out = d.dbg + (size_t)b * STAMP_WORDS;
+#pragma unroll
+        for (int k = 0; k < 20; k++) out[k] += st_acc[k];
+        out[20] += 1ull;
+        out[21] += t1 - st_t0;
+        out[22] += r1 - st_r0;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------

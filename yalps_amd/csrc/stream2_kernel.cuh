@@ -456,6 +456,17 @@ __global__ __launch_bounds__(T) void stream2_kernel(Desc d, int parity, int chun
                 *reinterpret_cast<double2 *>(prowN + c0) = make_double2((nzmask & (1u << (2 * j))) ? pv[j].x : flushed,
                                                                         (nzmask & (1u << (2 * j + 1))) ? pv[j].y : flushed);
         }
+        // The doubles behind column n of a device row are padding (rows are 128 bytes apart): the pass above has marked them
+        // FLUSHED like any other zero; the select-free path of the sweep multiplies every lane's units by this row, so the
+        // lane that holds them overwrites its own marks with a finite 0.0 (same lane, same address: in order).
+        {
+            const int u_first = n >> 1, d_lane = (tid - u_first) & (T - 1); // (T is a power of two)
+            if (d_lane < (pitch >> 1) - u_first) {
+                const int c0p = 2 * (u_first + d_lane);
+                if (c0p >= n) prowN[c0p] = 0.0;
+                prowN[c0p + 1] = 0.0;
+            }
+        }
         {
             const bool fast = __builtin_amdgcn_ballot_w64(((nzmask | padmask) & FULL) != FULL) == 0; // (per wave)
             if ((tid & 63) == 0) sh_fast[npend][tid >> 6] = fast ? 1 : 0;

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
     for (int j = 0; j < J; j++)
 #pragma unroll
         for (int k = 0; k < 2; k++)
-            if (2 * (tid + j * T) + k >= n) padmask |= 1u << (2 * j + k);
+            if (2 * (tid + j * T) + k >= (CHECK ? pitch : n)) padmask |= 1u << (2 * j + k); // (CHECK: see the padding note at the end of the pivot loop)
     constexpr unsigned FULL = J == 16 ? 0xFFFFFFFFu : (1u << (2 * (J & 15))) - 1u;
     // ---- my replica of the objective row (registers), my rows' RHS (LDS) ----
 #pragma unroll
@@ -355,6 +355,12 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
         __syncthreads();
     check();
     if (!stop) publish(candidate(phase));
+#ifdef YALPS_STAMPS
+    // diagnostic build: stage sums over the launch's pivots (stages: tools/stream3_stages.py)
+    unsigned long long st_acc[20] = {}, st_last = 0, st_t0 = 0, st_r0 = 0;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t0), "=s"(st_r0)::"memory");
+    st_last = st_t0;
+#endif
 
     while (!stop) {
         // ---------------- gather everyone's candidate -------------------------------------------
@@ -382,6 +388,7 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
         c = block_argmin<T>(c, sk, si, slot); // (its barrier is the one the polling waves join)
         slot ^= 1;
         if (sh_fail) return; // uniform: written before the barrier above
+        YSTAMP(0); // everybody's key record polled, arg-min (barrier)
         if (c.i == INT_MAX) {
             if (phase == 1) { // :120 phase 1 is over: same tableau, now the min-ratio exchange
                 phase = 2;
@@ -439,6 +446,7 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
         } else {
             rhs_row = ld_sc1(d.rc_key[par] + owner);
         }
+        YSTAMP(1); // two-step exchange: the winner's owner runs the row through the pending pivots and publishes it / the others wait for its record
         const __amdgpu_buffer_rsrc_t rsrc_src = rsrc_of(src);
         int col = la;
         if (phase == 1) { // :123-134, JC units of the raw row per lane at a time
@@ -510,6 +518,7 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
                 continue;
             }
         }
+        YSTAMP(2); // phase 1: entering column; checkCycles: verdict
         // ---------------- pivot (src/simplex.ts:5-39): it becomes pending pivot number npend ---------------------------
         const int colx = col - 1;
         double *prowN = prow0 + (size_t)npend * pitch, *colvN = colv0 + npend * rpw, *nqvN = nqv0 + npend * rpw;
@@ -523,6 +532,7 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
         }
         const double q = ld_sc1(src + colx), coef0 = olds[colx], inv_q = 1.0 / q;
         __syncthreads(); // (everybody has read olds[colx] before its owner patches it below)
+        YSTAMP(3); // my rows' pivot-column entries, quotient (two barriers)
         const bool nz_rhs = fabs(rhs_row) > 1e-16;
         const double pn_rhs = nz_rhs ? rhs_row / q : 0.0;
         for (int i = tid; i < my_rows; i += T) { // RHS entries of my rows (:33 at column 0)
@@ -535,6 +545,7 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
             }
             nqvN[i] = i == lslot ? inv_q : -coef / q; // what replaces the pivot column (:25, :36)
         }
+        YSTAMP(4); // RHS entries, what replaces the pivot column
         // one pass over the raw row, JC units per lane at a time: normalised -> my scratch (:14-25; FLUSHED marks what pivot()
         // zeroed), my objective replica updated (:27-38 for row 0), and priced (:71-79) while it is in registers
         const bool touched0 = fabs(coef0) > 1e-16;
@@ -583,6 +594,7 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
             if ((tid & 63) == 0) sh_fast[npend][tid >> 6] = fast ? 1 : 0;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (my scratch stores are out before the barrier below: other waves' scalar chains read them at L2)
+        YSTAMP(5); // the raw pivot row (sc1) -> normalised -> scratch, objective replica, priced; stores drained
         if (tid == 0) { // (published to the workgroup by price()'s barrier, like prow / rhsv)
             sh_pl[npend] = lslot;
             sh_pc[npend] = colx;
@@ -595,9 +607,12 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
         slot ^= 1;
         la = best.i == INT_MAX ? 0 : best.i;
         check();
+        YSTAMP(6); // arg-max of the pricing (barriers)
         if (!stop) {
             if (phase == 2) column_now(la - 1, lav); // my rows' entries of column la after every pivot so far
+            YSTAMP(7); // my rows' entries of the next entering column (scalar chains)
             publish(candidate(phase));               // (la > 0 here: check() stops phase 2 without an entering column)
+            YSTAMP(8); // my candidate (arg-min), its key record (single hand-off: + the row through the pending pivots)
         }
         if (b == 0 && tid == 0) { // basis bookkeeping, :7-12 (off the critical path)
             const int leaving = d.var[w + row], entering = d.var[col];
@@ -607,11 +622,38 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
             d.pos[entering] = w + row;
         }
         // ---------------- the rows: only every depth-th pivot (or on the way out) ----------------------------------------
+        // The doubles behind column n of a device row are padding (rows are 128 bytes apart): the pass over the pivot row has marked them
+        // FLUSHED like any other zero; the select-free path of the sweep multiplies every lane's units by this row, so the
+        // lane that holds them overwrites its own marks with a finite 0.0 (same lane, same address: in order).  The checkCycles
+        // forms have no register left for that (at 8 and 16 units per lane they would spill): there the one or two waves that
+        // hold padding never take the select-free path instead (padmask covers only the units beyond the pitch).
+        if constexpr (!CHECK) {
+            const int u_first = n >> 1, d_lane = (tid - u_first) & (T - 1); // (T is a power of two)
+            if (d_lane < (pitch >> 1) - u_first) {
+                const int c0p = 2 * (u_first + d_lane);
+                if (c0p >= n) (prow0 + (size_t)(npend - 1) * pitch)[c0p] = 0.0;
+                (prow0 + (size_t)(npend - 1) * pitch)[c0p + 1] = 0.0;
+            }
+        }
+        YSTAMP(9); // basis bookkeeping (workgroup 0)
         if (npend == depth || stop)
             flush_pending();
         else
             __syncthreads(); // (colv / rhsv / lav of this pivot are complete before the next round's lanes read them)
+        YSTAMP(10); // the sweep (every depth-th pivot) / barrier
     }
+#ifdef YALPS_STAMPS
+    if (tid == 0 && d.dbg) {
+        unsigned long long t1, r1;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1)::"memory");
+        unsigned long long *out = d.dbg + (size_t)b * STAMP_WORDS;
+#pragma unroll
+        for (int k = 0; k < 20; k++) out[k] += st_acc[k];
+        out[20] += (unsigned long long)done;
+        out[21] += t1 - st_t0;
+        out[22] += r1 - st_r0;
+    }
+#endif
     flush_pending(); // (a pivot decided before a break out of the loop: unbounded / infeasible leave with one pending)
 
     // ---------------- leave: RHS column, state (the rows are where they were) --------------------

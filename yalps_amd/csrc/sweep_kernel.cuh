@@ -436,6 +436,17 @@ __global__ __launch_bounds__(T) void sweep_kernel(Desc d, int parity, int chunk)
             *reinterpret_cast<double2 *>(prow + 2 * (tid + j * T)) = make_double2(nzx ? qx : flushed, nzy ? qy : flushed);
             __builtin_amdgcn_sched_barrier(0);
         }
+        // The doubles behind column n of a device row are padding (rows are 128 bytes apart): the pass above has marked them
+        // FLUSHED like any other zero; the select-free path of the sweep multiplies every lane's units by this row, so the
+        // lane that holds them overwrites its own marks with a finite 0.0 (same lane, same address: in order).
+        {
+            const int u_first = n >> 1, d_lane = (tid - u_first) & (T - 1); // (T is a power of two)
+            if (d_lane < (pitch >> 1) - u_first) {
+                const int c0p = 2 * (u_first + d_lane);
+                if (c0p >= n) prow[c0p] = 0.0;
+                prow[c0p + 1] = 0.0;
+            }
+        }
         const bool fast = __builtin_amdgcn_ballot_w64(((nzmask | padmask) & FULL) != FULL) == 0; // no entry of this wave was flushed
         const double inv_q = 1.0 / q; // :25
         const bool nz_rhs = fabs(rhs_row) > 1e-16;

@@ -34,6 +34,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <climits>
 #include <cmath>
@@ -173,31 +174,71 @@ constexpr int PERSISTENT_RETRY_AFTER = 8;
 // against those the launch has its bounded waits (common.cuh spin_expired) and the fall-back.
 struct DeviceLock {
     int fd;
-    explicit DeviceLock(int fd_) : fd(fd_) {
-        if (fd >= 0)
-            while (flock(fd, LOCK_EX) != 0 && errno == EINTR) {
+    bool held = false; // fd < 0 (no lock file): nothing to hold, the launch goes ahead
+    // Never waits without a bound: LOCK_NB + a deadline.  A holder that is stopped or hung (or a stranger sitting on the file)
+    // then costs this solve its persistent path (the caller falls back and counts a give-up), not its progress.
+    DeviceLock(int fd_, int wait_ms) : fd(fd_) {
+        if (fd < 0) {
+            held = true;
+            return;
+        }
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(wait_ms);
+        int nap_us = 20;
+        for (;;) {
+            if (flock(fd, LOCK_EX | LOCK_NB) == 0) {
+                held = true;
+                return;
             }
+            if (errno != EWOULDBLOCK && errno != EINTR) return; // (a lock that cannot be taken at all: treated as expired)
+            if (std::chrono::steady_clock::now() >= deadline) return;
+            usleep(nap_us);
+            nap_us = std::min(nap_us * 2, 1000);
+        }
     }
     ~DeviceLock() {
-        if (fd >= 0) (void)flock(fd, LOCK_UN);
+        if (fd >= 0 && held) (void)flock(fd, LOCK_UN);
     }
     DeviceLock(const DeviceLock &) = delete;
     DeviceLock &operator=(const DeviceLock &) = delete;
 };
+// Where the lock files live: YALPS_HIP_LOCK_DIR if set, else $XDG_RUNTIME_DIR, else /tmp/yalps_hip_<uid> (created 0700).
+// The directory must be a real directory of this user that nobody else can write to -- a lock file in a world-writable
+// directory could be pre-planted as a link to one of the user's own files.  (Processes of different users therefore do not
+// serialise with each other; against those, as against any foreign kernel, a launch has its bounded waits.)
+static bool private_dir_ok(const std::string &dir, bool create) {
+    if (create && mkdir(dir.c_str(), 0700) != 0 && errno != EEXIST) return false;
+    struct stat st;
+    if (lstat(dir.c_str(), &st) != 0) return false;
+    return S_ISDIR(st.st_mode) && st.st_uid == geteuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0;
+}
 int open_device_lock(int device) {
     char bus[64] = "";
     if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) std::snprintf(bus, sizeof bus, "dev%d", device);
     for (char *p = bus; *p; p++)
         if (*p == ':' || *p == '/' || *p == '.') *p = '_';
-    const char *dir = std::getenv("YALPS_HIP_LOCK_DIR");
-    const std::string path = std::string(dir && *dir ? dir : "/tmp") + "/yalps_hip_" + bus + ".lock";
-    const int fd = open(path.c_str(), O_RDWR | O_CREAT | O_CLOEXEC, 0666);
-    if (fd < 0) {
-        std::fprintf(stderr, "yalps_hip: cannot open %s (%s): persistent launches are not serialised between processes\n",
-                     path.c_str(), std::strerror(errno));
+    std::string dir;
+    const char *forced = std::getenv("YALPS_HIP_LOCK_DIR");
+    const char *xdg = std::getenv("XDG_RUNTIME_DIR");
+    if (forced && *forced)
+        dir = forced; // (the caller's choice and responsibility; the file checks below still apply)
+    else if (xdg && *xdg && private_dir_ok(xdg, false))
+        dir = xdg;
+    else {
+        dir = "/tmp/yalps_hip_" + std::to_string((unsigned long)geteuid());
+        if (!private_dir_ok(dir, true)) {
+            std::fprintf(stderr, "yalps_hip: %s is not a private directory of this user: persistent launches are not serialised between processes\n", dir.c_str());
+            return -1;
+        }
+    }
+    const std::string path = dir + "/yalps_hip_" + bus + ".lock";
+    const int fd = open(path.c_str(), O_RDWR | O_CREAT | O_CLOEXEC | O_NOFOLLOW, 0600);
+    struct stat st;
+    if (fd < 0 || fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_nlink != 1 || st.st_uid != geteuid()) {
+        std::fprintf(stderr, "yalps_hip: cannot use %s as a lock file (%s): persistent launches are not serialised between processes\n",
+                     path.c_str(), fd < 0 ? std::strerror(errno) : "not a regular single-link file of this user");
+        if (fd >= 0) (void)close(fd);
         return -1;
     }
-    (void)fchmod(fd, 0666); // (another user's process must be able to open it too; the umask may have narrowed the mode)
     return fd;
 }
 constexpr size_t LDS_DYNAMIC_MAX = 160 * 1024 - 2048;
@@ -242,6 +283,8 @@ struct yalps_ctx {
     int resident_skip = 0, inplace_skip = 0; // solves left before the path is tried again
     int64_t giveups = 0;
     int lock_fd = -1; // per-device lock file shared by every process that uses this library (persistent launches take turns)
+    int lock_wait_ms = 5000; // how long a persistent launch waits for it (YALPS_HIP_LOCK_WAIT_MS); expiry = a give-up
+    int64_t lock_giveups = 0;
     int resident_chunk = RESIDENT_CHUNK; // pivots per resident launch (YALPS_HIP_RESIDENT_CHUNK)
     int resident_fault = 0; // test hook: treat the N-th persistent launch on this context as failed (YALPS_HIP_RESIDENT_FAULT=N)
     int64_t persistent_launches = 0;
@@ -257,8 +300,16 @@ struct yalps_ctx {
     size_t small_blob_cap = 0;
 };
 
+// Every tableau object, and every re-partition of one, gets an identity that no other ever has: what a cached hipGraph of
+// the sharded loop (yalps_comm) is keyed by -- an address can come back after a destroy, device pointers change in set_shard.
+static uint64_t next_tableau_generation() {
+    static std::atomic<uint64_t> counter{0};
+    return ++counter;
+}
+
 struct yalps_tableau {
     yalps_ctx *ctx = nullptr;
+    uint64_t generation = next_tableau_generation();
     Desc d{};
     int32_t height = 0;
     int cur = 0; // tableau buffer holding the current tableau
@@ -460,26 +511,55 @@ int32_t yalps_device_count(void) {
 
 double yalps_round_to_precision(double num, double precision) { return round_to_precision(num, precision); }
 
-void yalps_dense_lp_f64(int32_t M, int32_t N, double seed, double *matrix) {
-    // tests/helpers/util.ts:20-41 of the reference: seed is a double, += 0x9e3779b9 unwrapped
-    auto next = [&seed]() {
+// dense-LP(M,N,seed), SURVEY.md 8(d).  tests/helpers/util.ts:20-41 of the reference: the seed is a double,
+// += 0x9e3779b9 unwrapped (beyond 2^53 the rounding of that sum is part of the definition, so the stream is walked
+// draw by draw even where rows are skipped); ToInt32(seed) = the integer value modulo 2^32.
+namespace {
+struct DenseLpStream {
+    double seed;
+    inline uint32_t step() { // the seed's low 32 bits after the increment
         seed += 2654435769.0;
-        uint32_t x = (uint32_t)(uint64_t)fmod(seed, 4294967296.0);
+        // (an integer-valued double below 2^63 converts exactly; fmod -- 50 x slower -- for anything else)
+        if (seed >= 0.0 && seed < 9223372036854775808.0 && seed == (double)(uint64_t)seed) return (uint32_t)(uint64_t)seed;
+        return (uint32_t)(uint64_t)fmod(seed, 4294967296.0);
+    }
+    inline double next() {
+        uint32_t x = step();
         x ^= x >> 16;
         x *= 0x21f0aaadu;
         x ^= x >> 15;
         x *= 0xd35a2d97u;
         x ^= x >> 15;
         return (double)x / 4294967296.0;
-    };
-    const int32_t w = N + 1, h = M + 1;
-    matrix[0] = 0.0;
-    for (int32_t j = 1; j < w; j++) matrix[j] = next();
-    for (int32_t r = 1; r < h; r++) {
-        double *mr = matrix + (size_t)r * w;
-        mr[0] = (double)N * 0.25 * (1.0 + next());
-        for (int32_t j = 1; j < w; j++) mr[j] = next();
     }
+};
+} // namespace
+
+void yalps_dense_lp_rows_f64(int32_t M, int32_t N, double seed, int32_t row_begin, int32_t row_end, double *rows) {
+    // rows [row_begin, row_end) of the (M+1) x (N+1) tableau (row 0 = objective row), row-major into `rows`; the draws of
+    // the rows before row_begin are walked (the seed only: a few cycles each), not hashed
+    const int32_t w = N + 1, h = M + 1;
+    DenseLpStream g{seed};
+    if (row_end > h) row_end = h;
+    for (int32_t r = 0; r < row_end; r++) {
+        const bool keep = r >= row_begin;
+        double *mr = keep ? rows + (size_t)(r - row_begin) * w : nullptr;
+        if (r == 0) {
+            if (keep) mr[0] = 0.0;
+        } else if (keep) {
+            mr[0] = (double)N * 0.25 * (1.0 + g.next());
+        } else {
+            g.seed += 2654435769.0;
+        }
+        if (keep)
+            for (int32_t j = 1; j < w; j++) mr[j] = g.next();
+        else
+            for (int32_t j = 1; j < w; j++) g.seed += 2654435769.0;
+    }
+}
+
+void yalps_dense_lp_f64(int32_t M, int32_t N, double seed, double *matrix) {
+    yalps_dense_lp_rows_f64(M, N, seed, 0, M + 1, matrix);
 }
 
 static int32_t ctx_create(int32_t device, void *ext_stream, bool adopt, yalps_ctx **out) {
@@ -517,6 +597,7 @@ static int32_t ctx_create(int32_t device, void *ext_stream, bool adopt, yalps_ct
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->small_res), sizeof(SmallResult), hipHostMallocDefault));
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; // measured 1-2 % faster in the pivot loop at 2049^2 and 4097^2
     c->lock_fd = env_int("YALPS_HIP_LOCK", 1) ? open_device_lock(device) : -1;
+    c->lock_wait_ms = std::max(0, env_int("YALPS_HIP_LOCK_WAIT_MS", 5000));
     c->max_blocks = env_int("YALPS_HIP_BLOCKS", prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
     if (c->max_blocks < 1) c->max_blocks = 1;
     if (c->max_blocks > MAX_BLOCKS) c->max_blocks = MAX_BLOCKS;
@@ -866,14 +947,14 @@ int32_t yalps_tableau_info(const yalps_tableau *t, char *buf, int32_t len) {
     else
         std::snprintf(str, sizeof str, "pivot_kernel<%d,%d,%d>", t->var.T, t->var.J, t->var.R);
     std::snprintf(buf, (size_t)len, "streaming=%s workgroups=%d resident=%s inplace=%s giveups=%lld resident_off_for=%d inplace_off_for=%d "
-                  "last_path=%s last_resident_launches=%lld node_fused_runs=%lld", str,
+                  "last_path=%s last_resident_launches=%lld node_fused_runs=%lld lock_giveups=%lld", str,
                   t->nb, res, inp, (long long)t->giveups, t->ctx->resident ? t->ctx->resident_skip : -1,
                   t->ctx->inplace ? t->ctx->inplace_skip : -1,
                   t->last_path == 1 ? "resident" : t->last_path == 2 ? "streaming" : t->last_path == 3 ? "resident+streaming"
                   : t->last_path == 4 ? "small" : t->last_path == 8 ? "inplace" : t->last_path == 10 ? "inplace+streaming"
                   : t->last_path == 9 ? "resident+inplace" : t->last_path == 11 ? "resident+inplace+streaming"
                   : t->last_path == 16 ? "generic" : "none",
-                  (long long)(t->last_path & 9 ? t->last_launches : 0), (long long)t->node_fused_runs);
+                  (long long)(t->last_path & 9 ? t->last_launches : 0), (long long)t->node_fused_runs, (long long)t->ctx->lock_giveups);
     return 0;
 }
 
@@ -890,6 +971,26 @@ int32_t yalps_tableau_debug_stamps(yalps_tableau *t, uint64_t *out, int32_t cap_
     (void)t, (void)out, (void)cap_words, (void)reset;
     return fail(YALPS_E_ARG, "yalps_tableau_debug_stamps: this is not the diagnostic build (-DYALPS_STAMPS)");
 #endif
+}
+
+int32_t yalps_tableau_padding_check(yalps_tableau *t, int64_t *nonfinite_out, int64_t *nonzero_out) {
+    // the pitch - n doubles behind every row of the current buffer (device rows are padded to 128 bytes; the padding is
+    // zero after an upload and no kernel has a reason to change it): how many of them are not finite / not zero now
+    if (!t || t->height < 1 || !nonfinite_out || !nonzero_out) return fail(YALPS_E_ARG, "yalps_tableau_padding_check: bad argument");
+    HIP_TRY(hipSetDevice(t->ctx->device));
+    HIP_TRY(hipStreamSynchronize(t->ctx->stream));
+    const Desc &d = t->d;
+    *nonfinite_out = *nonzero_out = 0;
+    const int pad = d.pitch - d.n;
+    if (pad <= 0) return 0;
+    std::vector<double> host((size_t)pad * (size_t)t->height);
+    HIP_TRY(hipMemcpy2D(host.data(), sizeof(double) * pad, d.mat[t->cur] + d.n, sizeof(double) * d.pitch, sizeof(double) * pad,
+                        (size_t)t->height, hipMemcpyDeviceToHost));
+    for (double v : host) {
+        if (!std::isfinite(v)) ++*nonfinite_out;
+        if (v != 0.0) ++*nonzero_out;
+    }
+    return 0;
 }
 
 int32_t yalps_tableau_upload(yalps_tableau *t, const double *matrix, int32_t height, const int32_t *pos,
@@ -1318,6 +1419,7 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
         }
         int parity = 0;
         int32_t *herr = reinterpret_cast<int32_t *>(&t->host_state[3]); // pinned scratch
+        bool lock_expired = false;
         for (;;) {
             HIP_TRY(hipMemsetAsync(t->rc_sync, 0, t->rc_sync_bytes, s)); // (flags, verdicts, tags -- epochs restart at 1 --, error word)
             if (checkCycles) { // room for every pivot this launch can record (no pause inside a persistent launch)
@@ -1354,7 +1456,9 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
                 // (threads) could each get half of the CUs and wait for the rest until their bounded spins give up:
                 // within this process, one at a time per device, from the launch to its completion.
                 std::lock_guard<std::mutex> one_grid(persistent_mutex(c->device));
-                DeviceLock one_grid_of_all_processes(c->lock_fd);
+                DeviceLock one_grid_of_all_processes(c->lock_fd, c->lock_wait_ms);
+                lock_expired = !one_grid_of_all_processes.held;
+                if (!lock_expired) { // (else nothing of this launch is enqueued but the copies aside)
                 pv.fn<<<dim3(t->nb), dim3(pv.T), shmem, s>>>(t->d, parity, chunk);
                 t->last_path |= in_place ? 8 : 1;
                 t->last_launches++;
@@ -1381,24 +1485,33 @@ int32_t yalps_tableau_solve(yalps_tableau *t, double precision, double maxPivots
                 }
                 std::memcpy(herr, t->host_ctl, sizeof(int32_t));
                 std::memcpy(&t->host_state[1], t->host_ctl + 16 + (size_t)(parity ^ 1) * sizeof(YState), sizeof(YState));
+                }
             }
             if (std::getenv("YALPS_HIP_DEBUG")) {
                 const YState &hs = t->host_state[1];
                 std::fprintf(stderr, "yalps_hip: persistent launch %lld err=%d status=%d phase=%d iter=%g pivots=%lld result=%g mbuf=%d chunk=%d\n",
                              (long long)t->last_launches, *herr, hs.status, hs.phase, hs.iter, (long long)hs.pivots, hs.result, hs.mbuf, chunk);
             }
-            if (*herr || (c->resident_fault > 0 && c->persistent_launches == c->resident_fault)) {
+            if (lock_expired) {
+                HIP_TRY(hipStreamSynchronize(s));
+                c->lock_giveups++;
+                *herr = 0;
+            }
+            if (lock_expired || *herr || (c->resident_fault > 0 && c->persistent_launches == c->resident_fault)) {
                 // a workgroup gave up waiting (grid not co-resident: somebody else's kernel holds CUs): carry on with the
                 // next path from the last consistent state (st[parity]; in place: the copy made above), say so, and
                 // leave this path alone for the next few solves of this context
                 c->giveups++;
                 t->giveups++;
-                std::fprintf(stderr, "yalps_hip: %s launch gave up waiting for its grid (device shared with other work?); "
+                std::fprintf(stderr, "yalps_hip: %s launch %s; "
                                      "falling back for this and the next %d solves (event %lld on this context)\n",
-                             in_place ? "stream_kernel" : "resident_kernel", PERSISTENT_RETRY_AFTER, (long long)c->giveups);
-                if (in_place)
+                             in_place ? "stream_kernel" : "resident_kernel",
+                             lock_expired ? "did not get the device's lock file in time (another process of this library holds it)"
+                                          : "gave up waiting for its grid (device shared with other work?)",
+                             PERSISTENT_RETRY_AFTER, (long long)c->giveups);
+                if (in_place || lock_expired) // (every persistent path needs the lock)
                     c->inplace_skip = PERSISTENT_RETRY_AFTER + 1;
-                else
+                if (!in_place || lock_expired)
                     c->resident_skip = PERSISTENT_RETRY_AFTER + 1;
                 if (backup)
                     HIP_TRY(hipMemcpyAsync(t->perm_block, t->perm_backup, sizeof(int32_t) * 2 * (size_t)t->perm_cap, hipMemcpyDeviceToDevice, s));
@@ -1576,7 +1689,16 @@ static int32_t node_fused_solve(yalps_tableau *dst, const yalps_tableau *root, i
     HIP_TRY(hipGetLastError());
     {
         std::lock_guard<std::mutex> one_grid(persistent_mutex(c->device));
-        DeviceLock one_grid_of_all_processes(c->lock_fd);
+        DeviceLock one_grid_of_all_processes(c->lock_fd, c->lock_wait_ms);
+        if (!one_grid_of_all_processes.held) { // the ordinary calls rebuild the node and take the next path
+            HIP_TRY(hipStreamSynchronize(s));
+            c->giveups++;
+            c->lock_giveups++;
+            c->resident_skip = PERSISTENT_RETRY_AFTER + 1;
+            std::fprintf(stderr, "yalps_hip: node solve did not get the device's lock file in time; falling back for this and the next %d solves\n",
+                         PERSISTENT_RETRY_AFTER);
+            return 0;
+        }
         pv.fn<<<dim3(dst->nb), dim3(pv.T), shmem, s>>>(dst->d, 0, c->resident_chunk);
         HIP_TRY(hipGetLastError());
         node_finish_kernel<<<dim3(8), dim3(256), 0, s>>>(dst->d, h, dst->perm_len, dst->perm_cap, (int)(16 + 2 * sizeof(YState)), dst->host_ctl,
@@ -1694,6 +1816,7 @@ int32_t yalps_tableau_set_shard(yalps_tableau *t, int32_t rank, int32_t nranks, 
     if (t->generic) return fail(YALPS_E_ARG, "yalps_tableau_set_shard: row shards wider than 16385 columns are not supported");
     HIP_TRY(hipSetDevice(t->ctx->device));
     hipStream_t s = t->ctx->stream;
+    t->generation = next_tableau_generation(); // (the device arrays below are reallocated: a batch captured before is stale)
     Desc &d = t->d;
     d.nshards = nranks;
     d.shard_rank = rank;
@@ -1903,6 +2026,7 @@ struct yalps_comm {
     hipGraphExec_t graph_exec = nullptr;     // one batch of pivots (select, all-gather, apply), captured once per tableau
     hipGraph_t graph = nullptr;
     const yalps_tableau *graph_for = nullptr;
+    uint64_t graph_generation = 0; // ... and which incarnation of it (yalps_tableau::generation): the graph holds its Desc by value
     int graph_steps = 0;
     bool graph_failed = false;
     int64_t collectives = 0, graph_replays = 0;
@@ -2029,7 +2153,7 @@ int32_t yalps_shard_run(yalps_tableau *t, yalps_comm *c, double precision, doubl
     for (int batch = 0;; batch++) {
         bool replayed = false;
         if (want_graph && batch >= 1 && !c->graph_failed) {
-            if (!c->graph_exec || c->graph_for != t || c->graph_steps != check_every) {
+            if (!c->graph_exec || c->graph_for != t || c->graph_generation != t->generation || c->graph_steps != check_every) {
                 if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
                 if (c->graph) (void)hipGraphDestroy(c->graph);
                 c->graph_exec = nullptr;
@@ -2060,6 +2184,7 @@ int32_t yalps_shard_run(yalps_tableau *t, yalps_comm *c, double precision, doubl
                 if (ok) {
                     c->graph = g;
                     c->graph_for = t;
+                    c->graph_generation = t->generation;
                     c->graph_steps = check_every;
                 } else {
                     if (g) (void)hipGraphDestroy(g);
