@@ -172,12 +172,14 @@ int32_t yalps_tableau_bench_sweep(yalps_tableau *t, int32_t row, int32_t col, in
  *     all-gather of yalps_shard_slot_doubles() doubles per rank   (caller: RCCL / torch.distributed)
  *     yalps_shard_apply(t, gathered)         -- every rank picks the same winner and eliminates
  * All calls only enqueue work on the context's stream; yalps_shard_poll synchronises and returns
- * the replicated status (-1 = still running).  checkCycles is not available in this mode. */
+ * the replicated status (-1 = still running).  checkCycles (src/simplex.ts:44-63,98,137): one more single-workgroup
+ * launch per pivot runs the detector on the pivot everybody is about to decide (permutations and history are replicated
+ * on every rank: no communication); the history grows inside yalps_shard_poll -- poll at least every 8192 pivots. */
 int32_t yalps_tableau_set_shard(yalps_tableau *t, int32_t rank, int32_t nranks, const int32_t *bounds,
                                 int32_t global_height, const int32_t *positionOfVariable,
                                 const int32_t *variableAtPosition);
 int64_t yalps_shard_slot_doubles(const yalps_tableau *t);
-int32_t yalps_shard_begin(yalps_tableau *t, double precision, double maxPivots);
+int32_t yalps_shard_begin(yalps_tableau *t, double precision, double maxPivots, int32_t checkCycles);
 int32_t yalps_shard_select(yalps_tableau *t, double *send_dev);
 int32_t yalps_shard_apply(yalps_tableau *t, const double *gathered_dev);
 int32_t yalps_shard_poll(yalps_tableau *t, int32_t *status_out, double *result_out, int64_t *pivots_out);
@@ -199,7 +201,7 @@ int32_t yalps_comm_create_host(yalps_ctx *ctx, yalps_allgather_fn fn, void *user
                                yalps_comm **out);
 void yalps_comm_destroy(yalps_comm *c);
 int32_t yalps_comm_info(const yalps_comm *c, char *buf, int32_t len);
-int32_t yalps_shard_run(yalps_tableau *t, yalps_comm *c, double precision, double maxPivots, int32_t check_every,
+int32_t yalps_shard_run(yalps_tableau *t, yalps_comm *c, double precision, double maxPivots, int32_t checkCycles, int32_t check_every,
                         int32_t *status_out, double *result_out, int64_t *pivots_out, float *gpu_ms_out);
 
 /* ---- batched branch-and-cut node evaluation (BASELINE config 4) ---------------

@@ -55,10 +55,22 @@ class NumpyShardOps:
                         if _better(key, g, *self.c_ratio):
                             self.c_ratio = (key, g)
 
-    def begin(self, precision, max_pivots):
+    def begin(self, precision, max_pivots, check_cycles=False):
         self.precision, self.max_pivots = precision, max_pivots
         self.phase, self.iter, self.pivots = 1, 0.0, 0
+        self.check_cycles, self.history = bool(check_cycles), []  # (the history is per phase: src/simplex.ts:67,107)
         self._scan()
+
+    def _has_cycle(self, row, col):
+        """src/simplex.ts:44-63 on the replicated basis: every rank runs it on the same pivot, no communication."""
+        if not self.check_cycles:
+            return False
+        h = self.history
+        h.append((int(self.var[self.w + row]), int(self.var[col])))
+        for length in range(6, len(h) // 2 + 1):
+            if all(h[len(h) - 1 - i] == h[len(h) - 1 - i - length] for i in range(length)):
+                return True
+        return False
 
     def select(self):
         s = self.send.numpy()
@@ -96,7 +108,7 @@ class NumpyShardOps:
                     if _better(R[g, 2], int(R[g, 3]), *best):
                         best = (R[g, 2], int(R[g, 3]))
                 if best[1] == NONE:
-                    self.phase, self.iter = 2, 0.0
+                    self.phase, self.iter, self.history = 2, 0.0, []
                     continue
                 row = best[1]
                 slot = R[self._owner(row)]
@@ -127,6 +139,9 @@ class NumpyShardOps:
             slot = R[self._owner(row)]
             prow, rhs_row = slot[HDR:HDR + n].copy(), slot[4]
             break
+        if self._has_cycle(row, col):  # :98,137
+            self.status, self.result = 3, math.nan
+            return
         # pivot (src/simplex.ts:5-39) on my rows, with the raw pivot row (rhs_row, prow)
         full = np.concatenate(([rhs_row], prow))
         q = full[col]
@@ -171,11 +186,11 @@ class NumpyDelayedShardOps(NumpyShardOps):
         super().__init__(*a)
         self.depth = depth
 
-    def begin(self, precision, max_pivots):
+    def begin(self, precision, max_pivots, check_cycles=False):
         self.rhs = self.m[:, 0].copy()  # current
         self.obj = self.m[0].copy()     # current (columns 1..)
         self.pend = []
-        super().begin(precision, max_pivots)
+        super().begin(precision, max_pivots, check_cycles)
 
     def _column_now(self, c):
         v = self.m[:, c].copy()
@@ -273,7 +288,7 @@ class NumpyDelayedShardOps(NumpyShardOps):
                     if _better(R[g, 2], int(R[g, 3]), *best):
                         best = (R[g, 2], int(R[g, 3]))
                 if best[1] == NONE:
-                    self.phase, self.iter = 2, 0.0
+                    self.phase, self.iter, self.history = 2, 0.0, []
                     continue
                 row = best[1]
                 slot = R[self._owner(row)]
@@ -303,6 +318,8 @@ class NumpyDelayedShardOps(NumpyShardOps):
             prow, rhs_row = slot[HDR:HDR + n].copy(), slot[4]
             colv = self.lav  # (the look-ahead priced exactly this column)
             break
+        if self._has_cycle(row, col):  # :98,137: this pivot is not carried out, the pending ones are
+            return stop(3, math.nan)
         full = np.concatenate(([0.0], prow))  # (column 0, the RHS, is handled on its own below)
         q = full[col]
         leaving, entering = self.var[self.w + row], self.var[col]

@@ -6,7 +6,8 @@ over the library's RCCL communicator, batches of 64 pivots captured into a hipGr
 objective row and of every rank's block of rows (full-size runs: the tableau is 2.1 GB).  `phase1`: the input of
 tests/test_hip_parity.py's sweep cases (one row "-a x <= -b", exact zeros) instead of the seed's parity.
 `c5:<variant>`: the input of tests/_c5.py (BASELINE config 5); rank 0 saves SHA-256 digests per block of 512 rows with
-their global row numbers, every rank's copy of the objective row, column 0 and the basis."""
+their global row numbers, every rank's copy of the objective row, column 0 and the basis.
+`npy:<file>[:check]`: the (M+1) x (N+1) tableau in <file> instead of a generated one; `:check` = options.checkCycles."""
 import os
 import sys
 
@@ -34,14 +35,19 @@ def main():
     from yalps_amd import sharded
     w, h = N + 1, M + 1
     c5 = sys.argv[7][3:] if len(sys.argv) > 7 and sys.argv[7].startswith("c5:") else None
-    if c5:
+    npy = sys.argv[7][4:] if len(sys.argv) > 7 and sys.argv[7].startswith("npy:") else None
+    check_cycles = bool(npy) and npy.endswith(":check")
+    if npy:
+        m = np.load(npy[:-6] if check_cycles else npy).astype(np.float64).reshape(-1)
+        assert m.size == w * h
+    elif c5:
         from tests import _c5
         from yalps_amd import _native
         assert (M, N, seed) == (_c5.M, _c5.N, _c5.SEED)
         m = _c5.make_input(_native.dense_lp, c5)
     else:
         m = _oracle.load().dense_lp(M, N, seed)
-    if c5:
+    if c5 or npy:
         pass
     elif digest:  # (the full-size test's input: one row "-a x <= -b", so that the first pivot is a phase-1 pivot)
         m.reshape(h, w)[h // 3] *= -1.0
@@ -68,12 +74,14 @@ def main():
     if kind in ("hip-native", "hip-rccl"):  # (hip-rccl: one rank per GPU -- RCCL refuses ranks that share a device)
         transport = "host" if kind == "hip-native" else "rccl"
         ncomm = sharded.native_comm(ops.ctx, rank, world, transport=transport)
-        status, result, pivots = sharded.sharded_simplex_native(ops, ncomm, max_pivots=max_pivots, check_every=8 if kind == "hip-native" else 64)
+        status, result, pivots = sharded.sharded_simplex_native(ops, ncomm, max_pivots=max_pivots, check_every=8 if kind == "hip-native" else 64,
+                                                                check_cycles=check_cycles)
         assert ncomm.info()["transport"] == transport and int(ncomm.info()["collectives"]) >= pivots
         ncomm.close()
     else:
         comm = sharded.TorchComm()
-        status, result, pivots = sharded.sharded_simplex(ops, comm, max_pivots=max_pivots, check_every=8 if max_pivots > 8 else 1)
+        status, result, pivots = sharded.sharded_simplex(ops, comm, max_pivots=max_pivots, check_every=8 if max_pivots > 8 else 1,
+                                                         check_cycles=check_cycles)
     lap("solve done: %s, %d pivots" % (status, pivots))
     kernel = kind if kind.startswith("numpy") else ops.tab.info()["streaming"]
     lm, pos, var = ops.download()

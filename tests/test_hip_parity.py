@@ -793,6 +793,54 @@ def test_launch_per_pivot_fallback_variants(nat, oracle, monkeypatch, M, N, kern
     assert np.array_equal(got.view(np.int64), ref.view(np.int64))
 
 
+SPILLING = [  # M, N, checkCycles, env, streaming kernel, DECIDE kernel -- the seven launch-per-pivot instantiations with scratch
+    (2000, 2000, False, {}, "pivot_kernel<1024,1,9>", None),          # 12 B (bench.py's streaming_apply_only kernel)
+    (4000, 2000, False, {}, "pivot_kernel<1024,1,16>", None),         # 200 B
+    (4000, 500, False, {}, "pivot_kernel<256,1,16>", None),           # 20 B
+    (1500, 3000, True, {}, "wide_kernel<1024,2>", "pivot_kernel<1024,2,8>"),   # 348 B, DECIDE launches only
+    (900, 7000, True, {}, "wide_kernel<1024,4>", "pivot_kernel<1024,4,4>"),    # 452 B, DECIDE launches only
+    (300, 12000, True, {"YALPS_HIP_WIDE8": "1"}, "wide_kernel<1024,8>", "pivot_kernel<1024,8,2>"),  # 868 B DECIDE; wide_kernel<1024,8> 32 B
+    (300, 12000, False, {"YALPS_HIP_WIDE8": "1"}, "wide_kernel<1024,8>", None),
+]
+
+
+@pytest.mark.parametrize("M,N,check,env,kernel,decide", SPILLING)
+def test_every_spilling_launch_per_pivot_instantiation(nat, monkeypatch, M, N, check, env, kernel, decide):
+    """the register gate (yalps_amd/build.py NO_SCRATCH) exempts the launch-per-pivot family; seven of its
+    instantiations use scratch (12 - 868 bytes per lane).  Each of them by name: 48 pivots with a phase-1 start and exact
+    zeros against the oracle, every bit of the tableau (checkCycles where the instantiation only runs as the DECIDE launch)."""
+    from tests import _oracle
+    orc = _oracle.load(omp=True)
+    orc.set_threads(8)
+    monkeypatch.setenv("YALPS_HIP_RESIDENT", "0")
+    monkeypatch.setenv("YALPS_HIP_INPLACE", "0")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    c = nat.Context(0)
+    w, h = N + 1, M + 1
+    m = nat.dense_lp(M, N, 23)
+    A = m.reshape(h, w)
+    A[h // 3] *= -1.0
+    A[5::7, 3::5] = 0.0
+    pos, var = np.arange(w + h, dtype=np.int32), np.arange(w + h, dtype=np.int32)
+    ref, rpos, rvar = m.copy(), pos.copy(), var.copy()
+    est, eres, epiv, _ = orc.simplex(ref, w, h, rpos, rvar, max_pivots=48.0, check_cycles=check)
+    t = nat.DeviceTableau(c, w, h)
+    try:
+        t.upload(m, h, pos, var)
+        status, result, npiv, _ = t.solve(max_pivots=48, check_cycles=check)
+        info = t.info()
+        got, gpos, gvar = t.download()
+    finally:
+        t.close()
+        c.close()
+    assert info["last_path"] == "streaming" and info["streaming"] == kernel, info
+    assert decide is None or info["decide"] == decide, info
+    assert (status, npiv) == (est, epiv) and G.same_number(result, eres)
+    assert np.array_equal(gpos, rpos) and np.array_equal(gvar, rvar)
+    assert np.array_equal(got.view(np.int64), ref.view(np.int64))
+
+
 def test_golden_cases_through_the_inplace_kernel(nat, oracle, monkeypatch):
     """Every golden record of the reference (all statuses, checkCycles, odd precisions / maxPivots) through
     stream_kernel: a context without the single-workgroup and the register-resident paths."""

@@ -83,26 +83,48 @@ def test_sparse_family_through_stream3(monkeypatch, omp_oracle, case, nt):
     assert pad == (0, 0), pad
 
 
+DSHARD_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, %(root)r)
+import torch
+torch.cuda.init()  # (torch's HIP runtime first, as in every multi-rank launch: the other order leaves torch without a GPU)
+from yalps_amd import sharded
+m = np.load(%(inp)r)
+h, w, budget = %(h)d, %(w)d, %(budget)d
+pos = np.arange(w + h, dtype=np.int32)
+ops = sharded.HipShardOps(m, w, sharded.partition(h, 1), 0, h, pos, pos.copy(), device=0)
+status, result, npiv = sharded.sharded_simplex(ops, sharded.TorchComm(), max_pivots=float(budget), check_every=8)
+kernel = ops.tab.info()["streaming"]
+got, gpos, gvar = ops.download()
+pad = ops.tab.padding_check()
+ops.close()
+np.savez(%(out)r, matrix=got, pos=gpos, var=gvar, status=status, result=result, pivots=npiv, kernel=kernel, pad=np.array(pad))
+print("ok")
+"""
+
+
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "seed%d-%dx%d" % c[:3])
-def test_sparse_family_through_dshard(monkeypatch, omp_oracle, case):
+def test_sparse_family_through_dshard(monkeypatch, omp_oracle, tmp_path, case):
     """The same tableaux as ONE row shard (rank 0 of 1) through dshard_select_kernel / dshard_kernel<512,16>, depth 8, the
     Python loop with the status polled every 8 pivots: every pending row is stored by one launch and read by later ones --
-    the launch boundary dshard_kernel.cuh relies on for its single `d.dpend`."""
-    from yalps_amd import sharded
-    monkeypatch.setenv("YALPS_HIP_DELAY_DEPTH", "8")
+    the launch boundary dshard_kernel.cuh relies on for its single `d.dpend`.  (In a child process: the candidate slots are
+    torch tensors, and torch has to initialise its HIP runtime before the library does.)"""
+    import os
+    import subprocess
+    import sys
     seed, h, w, *_ , budget = case
     m, pos, var, ref, rpos, rvar, est, eres, epiv = _expect(omp_oracle, case)
-    bounds = sharded.partition(h, 1)
-    ops = sharded.HipShardOps(m, w, bounds, 0, h, pos, var, device=0)
-    try:
-        status, result, npiv = sharded.sharded_simplex(ops, sharded.TorchComm(), max_pivots=float(budget), check_every=8)
-        kernel = ops.tab.info()["streaming"]
-        got, gpos, gvar = ops.download()
-        pad = ops.tab.padding_check()
-    finally:
-        ops.close()
+    inp, out = str(tmp_path / "in.npy"), str(tmp_path / "out.npz")
+    np.save(inp, m)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, YALPS_HIP_DELAY_DEPTH="8", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    run = subprocess.run([sys.executable, "-c", DSHARD_CHILD % dict(root=root, inp=inp, out=out, h=h, w=w, budget=budget)],
+                         capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert run.returncode == 0 and "ok" in run.stdout, run.stdout + run.stderr
+    res = np.load(out)
+    kernel = str(res["kernel"])
     assert kernel.startswith("dshard_kernel<512,16") and kernel.endswith("delay_depth:8"), kernel
-    assert (status, npiv) == (est, epiv) and G.same_number(result, eres), (status, npiv, est, epiv)
-    assert np.array_equal(gpos, rpos) and np.array_equal(gvar, rvar)
-    assert np.array_equal(got.view(np.int64), ref.view(np.int64))
-    assert pad == (0, 0), pad
+    assert (str(res["status"]), int(res["pivots"])) == (est, epiv) and G.same_number(float(res["result"]), eres), (res["status"], res["pivots"], est, epiv)
+    assert np.array_equal(res["pos"], rpos) and np.array_equal(res["var"], rvar)
+    assert np.array_equal(res["matrix"].view(np.int64), ref.view(np.int64))
+    assert tuple(res["pad"]) == (0, 0), res["pad"]

@@ -23,6 +23,9 @@ os.environ["YALPS_HIP_LIB"] = os.path.join(ROOT, "yalps_amd", "libyalps_hip_stam
 
 import numpy as np  # noqa: E402
 
+if "dshard" in sys.argv:  # (the shard driver's slots are torch tensors: torch's HIP runtime has to be initialised first)
+    import torch  # noqa: E402
+    torch.cuda.init()
 from yalps_amd import _native  # noqa: E402
 
 STAGES = {

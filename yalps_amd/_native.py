@@ -78,7 +78,7 @@ def lib():
         L.yalps_shard_slot_doubles.restype = C.c_int64
         L.yalps_shard_slot_doubles.argtypes = [vp]
         L.yalps_shard_begin.restype = C.c_int32
-        L.yalps_shard_begin.argtypes = [vp, C.c_double, C.c_double]
+        L.yalps_shard_begin.argtypes = [vp, C.c_double, C.c_double, C.c_int32]
         L.yalps_shard_select.restype = C.c_int32
         L.yalps_shard_select.argtypes = [vp, vp]
         L.yalps_shard_apply.restype = C.c_int32
@@ -96,7 +96,7 @@ def lib():
         L.yalps_comm_info.restype = C.c_int32
         L.yalps_comm_info.argtypes = [vp, C.c_char_p, C.c_int32]
         L.yalps_shard_run.restype = C.c_int32
-        L.yalps_shard_run.argtypes = [vp, vp, C.c_double, C.c_double, C.c_int32, C.POINTER(C.c_int32), f64p,
+        L.yalps_shard_run.argtypes = [vp, vp, C.c_double, C.c_double, C.c_int32, C.c_int32, C.POINTER(C.c_int32), f64p,
                                       C.POINTER(C.c_int64), C.POINTER(C.c_float)]
         L.yalps_batch_create.restype = C.c_int32
         L.yalps_batch_create.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
@@ -332,8 +332,8 @@ class DeviceTableau:
     def shard_slot_doubles(self):
         return int(lib().yalps_shard_slot_doubles(self.handle))
 
-    def shard_begin(self, precision, max_pivots):
-        check(lib().yalps_shard_begin(self.handle, precision, float(max_pivots)))
+    def shard_begin(self, precision, max_pivots, check_cycles=False):
+        check(lib().yalps_shard_begin(self.handle, precision, float(max_pivots), int(bool(check_cycles))))
 
     def shard_select(self, send_ptr):
         check(lib().yalps_shard_select(self.handle, C.c_void_p(send_ptr)))
@@ -341,11 +341,11 @@ class DeviceTableau:
     def shard_apply(self, gathered_ptr):
         check(lib().yalps_shard_apply(self.handle, C.c_void_p(gathered_ptr)))
 
-    def shard_run(self, comm, precision=1e-8, max_pivots=8192.0, check_every=64):
+    def shard_run(self, comm, precision=1e-8, max_pivots=8192.0, check_every=64, check_cycles=False):
         """The whole row-sharded solve natively (yalps_shard_run): no Python between two pivots.
         Returns (status code, result, n_pivots, gpu_ms)."""
         st, res, npiv, ms = C.c_int32(), C.c_double(), C.c_int64(), C.c_float()
-        check(lib().yalps_shard_run(self.handle, comm.handle, precision, float(max_pivots), int(check_every), C.byref(st),
+        check(lib().yalps_shard_run(self.handle, comm.handle, precision, float(max_pivots), int(bool(check_cycles)), int(check_every), C.byref(st),
                                     C.byref(res), C.byref(npiv), C.byref(ms)))
         return st.value, res.value, npiv.value, ms.value
 

@@ -49,10 +49,13 @@ struct alignas(16) DelayState {
     int32_t npend;     // pivots decided whose eliminations have not been carried out on this rank's rows
     int32_t lav_valid; // d.dlav holds my rows' entries of column YState::la as they are now
     int32_t pad_[2];
-    int32_t pl[8]; // per pending pivot, oldest first: the pivot row as a LOCAL row of this rank (-1: another rank's)
-    int32_t pc[8]; // ... its pivot column (mat index)
-    int32_t fast[8]; // ... bit w: wave w's slice of its normalised row holds no FLUSHED mark (:31's select-free path; the same in every workgroup)
+    int32_t pl[16]; // per pending pivot, oldest first: the pivot row as a LOCAL row of this rank (-1: another rank's)
+    int32_t pc[16]; // ... its pivot column (mat index)
 };
+constexpr int STREAM3_MAXD = 16;         // pending pivots stream3_kernel can hold (the depth in use is Desc::delay_depth)
+constexpr int STREAM3_PANEL_UNITS = 512; // 16-byte units of a row per LDS panel of its sweep (panel_flush.cuh): 1024 columns
+constexpr int DSHARD_MAXD = 16;          // pending pivots a row shard can hold (dshard_kernel.cuh); the depth in use is Desc::delay_depth
+constexpr int DSHARD_PANEL_UNITS = 512;  // 16-byte units of a row per LDS panel of its sweep (panel_flush.cuh): 1024 columns
 
 struct alignas(16) Part {
     double key;
@@ -106,6 +109,9 @@ struct Desc {
     // entries of the next entering column [hcap], the pending pivots' rows / columns [2] by launch parity
     double *dpend, *dcolv, *dnqv, *dlav;
     DelayState *dstate;
+    // row shards with checkCycles: shard_cycle_kernel's verdict on the pivot the step launch of the same parity is about to
+    // carry out ([2] by launch parity; 1 = hasCycle, src/simplex.ts:98,137)
+    int32_t *cyc_verdict;
     // diagnostic build only (-DYALPS_STAMPS, never the shipped library): [nb][STAMP_WORDS] per-workgroup stage sums in
     // shader cycles, written once when a persistent launch ends; no kernel reads it
     unsigned long long *dbg;

@@ -14,6 +14,8 @@
 // each with its own separately rounded multiply and subtract in the reference's order: bit for bit what that many sweeps
 // leave (src/simplex.ts:5-39).  The candidate rows a rank sends get the pending pivots applied on their way into the
 // all-gather slot (dshard_select_kernel): what travels is the row as the reference would hold it.
+// The sweep itself is panel_flush.cuh: the pending rows pass through LDS one column panel at a time (round 3; up to
+// DSHARD_MAXD = 16 pending pivots of 1024 columns).
 // State between launches lives in global memory (LDS does not survive a launch): d.dstate[parity] {npend, the pending
 // pivots' rows and columns}, d.dcolv / d.dnqv [depth][hcap], d.dlav [hcap], d.dpend [depth][pitch].  ONE copy of the
 // pending rows serves all XCDs here (stream3_kernel needs one per XCD): every workgroup stores the same bytes, reads back
@@ -24,15 +26,11 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
     __shared__ double sk[2][16];
     __shared__ int si[2][16];
     __shared__ int sh_nt;
-    constexpr int MAXD = 8;
+    constexpr int MAXD = DSHARD_MAXD;
     __shared__ int sh_pl[MAXD], sh_pc[MAXD]; // the pending pivots, oldest first: my slot of the pivot row (-1: not mine), pivot column (mat index)
-    __shared__ int sh_fast[MAXD][T / 64];    // per wave: nothing of its slice of that pivot row was flushed (:31 select-free path)
     constexpr int JC = J > 8 ? 8 : J;        // units per lane that pass through registers at a time (a pivot row being decided)
-#ifndef YALPS_DSHARD_JA16
-#define YALPS_DSHARD_JA16 8
-#endif
-    constexpr int JA = J > 8 ? YALPS_DSHARD_JA16 : J; // ... of a pending pivot row while it is applied to the rows in flight
-    extern __shared__ __attribute__((aligned(16))) double sm_dyn[]; // colv[depth][rpw], nqv[depth][rpw], lav[rpw], rhsv[rpw], tlist[rpw] (int)
+    constexpr int PU = DSHARD_PANEL_UNITS;   // 16-byte units of a row per panel of the sweep (panel_flush.cuh)
+    extern __shared__ __attribute__((aligned(16))) double sm_dyn[]; // colv[depth][rpw], nqv[depth][rpw], lav[rpw], rhsv[rpw], tlist[rpw] (int), panel[depth][2 PU]
 
     const int tid = threadIdx.x, NB = d.nb, b = blockIdx.x;
 #ifdef YALPS_STAMPS
@@ -70,6 +68,7 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
     const int depth = d.delay_depth < 1 ? 1 : d.delay_depth > MAXD ? MAXD : d.delay_depth;
     double *colv0 = sm_dyn, *nqv0 = colv0 + (size_t)depth * rpw, *lav = nqv0 + (size_t)depth * rpw, *rhsv = lav + rpw;
     int *tlist = reinterpret_cast<int *>(rhsv + rpw);
+    double *panel = rhsv + rpw + (rpw + 3) / 4 * 2; // (behind tlist, 16-byte aligned: rpw ints rounded up to a multiple of four)
     const double flushed = __longlong_as_double((long long)FLUSHED);
     double *const prow0 = d.dpend;
     int npend = Din->npend;
@@ -96,20 +95,12 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
     };
 
     // ---- what the earlier launches left: the pending pivots' scalars for my rows, my rows' RHS and look-ahead column ----
+    static_assert(MAXD <= T, "one lane per pending pivot");
     if (tid < MAXD) {
         const int lr = tid < npend ? Din->pl[tid] : -1;
         sh_pl[tid] = (lr >= 0 && lr % NB == b) ? lr / NB : -1;
         sh_pc[tid] = tid < npend ? Din->pc[tid] : 0;
-        const int fm = tid < npend ? Din->fast[tid] : 0;
-        for (int wv = 0; wv < T / 64; wv++) sh_fast[tid][wv] = (fm >> wv) & 1;
     }
-    unsigned padmask = 0; // columns of mine that do not exist (c0 + k >= n): 0.0 in a pivot row, must not count as "flushed"
-#pragma unroll
-    for (int j = 0; j < J; j++)
-#pragma unroll
-        for (int k = 0; k < 2; k++)
-            if (2 * (tid + j * T) + k >= n) padmask |= 1u << (2 * j + k);
-    constexpr unsigned FULL = J == 16 ? 0xFFFFFFFFu : (1u << (2 * (J & 15))) - 1u;
     for (int i = tid; i < my_rows; i += T) {
         const int r = b + NB * i;
         for (int p = 0; p < npend; p++) {
@@ -142,82 +133,20 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
         int t0 = tid;
         asm volatile("" : "+v"(t0));
         for (int i = t0; i < my_rows; i += T) {
-            double pe[MAXD];
             double v = __hip_atomic_load(mat + (size_t)(b + NB * i) * pitch + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll 1
+            for (int p0 = 0; p0 < npend; p0 += 8) { // (eight pending pivots' entries in flight at a time: registers)
+                double pe[8];
 #pragma unroll
-            for (int p = 0; p < MAXD; p++)
-                pe[p] = p < npend ? __hip_atomic_load(prow0 + (size_t)p * pitch + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+                for (int p = 0; p < 8; p++)
+                    pe[p] = p0 + p < npend ? __hip_atomic_load(prow0 + (size_t)(p0 + p) * pitch + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
 #pragma unroll
-            for (int p = 0; p < MAXD; p++)
-                if (p < npend) v = after1(pe[p], colv0 + p * rpw, nqv0 + p * rpw, sh_pl[p], sh_pc[p], i, v, c);
+                for (int p = 0; p < 8; p++)
+                    if (p0 + p < npend) v = after1(pe[p], colv0 + (p0 + p) * rpw, nqv0 + (p0 + p) * rpw, sh_pl[p0 + p], sh_pc[p0 + p], i, v, c);
+            }
             out[i] = v;
         }
         __syncthreads();
-    };
-    // the pending pivots applied to (up to) RB half-rows held in registers: units [u0, u0 + JH) of my row slots ri[0 .. cnt)
-    #ifndef YALPS_DSHARD_RB16
-#define YALPS_DSHARD_RB16 4
-#endif
-    constexpr int JH = J > 8 ? 8 : J, RB = J > 8 ? YALPS_DSHARD_RB16 : 3; // (a chunk of a pending row is read once per RB half-rows: L2 reads, not HBM, bound the sweep)
-    auto apply_batch = [&](int u0, double2 (&xb)[RB][JH], const int (&ri)[RB], int cnt) __attribute__((always_inline)) {
-#pragma unroll 1
-        for (int p = 0; p < npend; p++) {
-            const __amdgpu_buffer_rsrc_t rsp = rsrc_of(prow0 + (size_t)p * pitch);
-            const int colxp = sh_pc[p], lslotp = sh_pl[p];
-            const bool fastp = sh_fast[p][tid >> 6] != 0;
-            // the one element of a row that the pivot column replaces (:25, :36): unit `up` of lane `lp` -- the unit is the same
-            // for every lane, so all but one of the unrolled units skip the patch on a scalar compare
-            const int up = (colxp >> 1) / T;
-            const bool lane_p = ((colxp >> 1) % T) == tid;
-            double coefu[RB], patchu[RB];
-            bool pivu[RB], actu[RB];
-#pragma unroll
-            for (int u = 0; u < RB; u++) {
-                coefu[u] = colv0[p * rpw + ri[u]];
-                patchu[u] = nqv0[p * rpw + ri[u]];
-                pivu[u] = ri[u] == lslotp;
-                actu[u] = u < cnt && (pivu[u] || fabs(coefu[u]) > 1e-16); // :31
-            }
-#pragma unroll
-            for (int jb = 0; jb < JH; jb += JA) {
-                double2 pn[JA];
-#pragma unroll
-                for (int j = 0; j < JA; j++) pn[j] = row_ld16<AUX_PLAIN>(rsp, lane_off + 16 * T * (u0 + jb + j), 0);
-#pragma unroll
-                for (int u = 0; u < RB; u++) {
-                    if (!actu[u]) continue; // (uniform)
-#pragma unroll
-                    for (int j = 0; j < JA; j++) {
-                        double2 &xv = xb[u][jb + j];
-                        if (fastp && !pivu[u]) {
-                            const double px = coefu[u] * pn[j].x, py = coefu[u] * pn[j].y;
-                            xv.x = xv.x - px;
-                            xv.y = xv.y - py;
-                        } else {
-                            const bool f0 = (unsigned long long)__double_as_longlong(pn[j].x) != FLUSHED;
-                            const bool f1 = (unsigned long long)__double_as_longlong(pn[j].y) != FLUSHED;
-                            if (pivu[u]) {
-                                xv.x = f0 ? pn[j].x : 0.0;
-                                xv.y = f1 ? pn[j].y : 0.0;
-                            } else {
-                                const double px = coefu[u] * pn[j].x, py = coefu[u] * pn[j].y;
-                                const double nx = xv.x - px, ny = xv.y - py;
-                                xv.x = f0 ? nx : xv.x;
-                                xv.y = f1 ? ny : xv.y;
-                            }
-                        }
-                        if (up == u0 + jb + j) { // (uniform)
-                            if (lane_p) {
-                                if (colxp & 1)
-                                    xv.y = patchu[u];
-                                else
-                                    xv.x = patchu[u];
-                            }
-                        }
-                    }
-                }
-            }
-        }
     };
     // every touched row of mine streamed once, all pending eliminations in registers; afterwards nothing is pending
     auto flush_pending = [&]() __attribute__((always_inline)) {
@@ -236,33 +165,8 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
             if (tid == 0) sh_nt = cnt;
         }
         __syncthreads();
-        const int nt = sh_nt;
-#pragma unroll 1
-        for (int u0 = 0; u0 < J; u0 += JH) {
-#pragma unroll 1
-            for (int k = 0; k < nt; k += RB) {
-                double2 xb[RB][JH];
-                int ri[RB];
-#pragma unroll
-                for (int u = 0; u < RB; u++) {
-                    ri[u] = tlist[k + u < nt ? k + u : k];
-                    const __amdgpu_buffer_rsrc_t rs = rsrc_of(mat + (size_t)(b + NB * ri[u]) * pitch);
-                    if (k + u < nt) {
-#pragma unroll
-                        for (int j = 0; j < JH; j++) xb[u][j] = row_ld16<NT ? AUX_NT : AUX_PLAIN>(rs, lane_off + 16 * T * (u0 + j), 0);
-                    }
-                }
-                apply_batch(u0, xb, ri, nt - k);
-#pragma unroll
-                for (int u = 0; u < RB; u++) {
-                    if (k + u < nt) {
-                        const __amdgpu_buffer_rsrc_t rs = rsrc_of(mat + (size_t)(b + NB * ri[u]) * pitch);
-#pragma unroll
-                        for (int j = 0; j < JH; j++) row_st16<NT ? AUX_NT : AUX_PLAIN>(rs, lane_off + 16 * T * (u0 + j), 0, xb[u][j]);
-                    }
-                }
-            }
-        }
+        // (panel_flush.cuh: the pending rows staged in LDS one column panel at a time, four rows in flight per lane)
+        panel_flush<T, PU, 4, NT>(mat, pitch, b, NB, prow0, npend, colv0, nqv0, rpw, sh_pl, sh_pc, tlist, sh_nt, panel, rsrc_of);
         npend = 0;
     };
     auto write_state = [&](int status, int phase_, int la_, int pbuf_, int swap_valid_, int swap_row_, int swap_col_, int64_t hist_len_,
@@ -384,11 +288,13 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
             break;
         }
     }
+    const int check = C->check_cycles ? 1 : 0;
+    if (term == RUNNING && check && d.cyc_verdict[parity & 1]) term = YALPS_CYCLED; // :98,137: shard_cycle_kernel's verdict on this pivot
     YSTAMP(1); // decide (the gathered records, phase 1: the entering column)
     if (term != RUNNING) { // the solve ends here: the pending pivots are carried out on the way out
         flush_pending();
         if (b == 0 && tid == 0) {
-            write_state(term, phase, la_in, pbuf, 0, 0, 0, phase_switched ? 0 : hist_len_in, iter, term_result, pivots_in);
+            write_state(term, phase, la_in, pbuf, 0, 0, 0, (phase_switched ? 0 : hist_len_in) + (term == YALPS_CYCLED ? check : 0), iter, term_result, pivots_in);
             DelayState z = {};
             *Dout = z;
         }
@@ -434,7 +340,6 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
     const double nq0 = -coef0 / q; // :36 for the objective row
     const __amdgpu_buffer_rsrc_t rsrc_src = rsrc_of(mrow), rsrc_new = rsrc_of(prow0 + (size_t)npend * pitch), rs_objB = rsrc_of(objB);
     KI best = {INFINITY, INT_MAX};
-    unsigned nzmask = 0;
 #pragma unroll 1
     for (int jb = 0; jb < J; jb += JC) {
         double2 pv[JC], ob[JC];
@@ -453,7 +358,6 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
                 const bool nzk = fabs(v) > 1e-16;
                 const double vn = nzk ? v / q : 0.0;
                 pn = with_elem(pn, k, nzk ? vn : flushed);
-                if (nzk) nzmask |= 1u << (2 * (jb + j) + k);
                 double o1 = elem(ov, k);
                 if (touched0) {
                     if (c0 + k == colx)
@@ -483,10 +387,6 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
             if (c0p >= n) (prow0 + (size_t)npend * pitch)[c0p] = 0.0;
             (prow0 + (size_t)npend * pitch)[c0p + 1] = 0.0;
         }
-    }
-    {
-        const bool fast = __builtin_amdgcn_ballot_w64(((nzmask | padmask) & FULL) != FULL) == 0; // (per wave)
-        if ((tid & 63) == 0) sh_fast[npend][tid >> 6] = fast ? 1 : 0;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (my stores of the pending row are out before the barrier below: the scalar chains read them at L2)
     YSTAMP(4); // the pivot row: normalised + stored, objective replica, priced in registers
@@ -549,16 +449,13 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
     // ---------------- the rows: only every depth-th pivot ------------------------------------------------------------------
     const int npend_out = npend == depth ? 0 : npend;
     if (b == 0 && tid == 0) {
-        write_state(RUNNING, phase, la, pbuf ^ 1, 1, row, col, phase_switched ? 0 : hist_len_in, iter + 1.0, NAN, pivots_in + 1);
+        write_state(RUNNING, phase, la, pbuf ^ 1, 1, row, col, (phase_switched ? 0 : hist_len_in) + check, iter + 1.0, NAN, pivots_in + 1);
         DelayState o = {};
         o.npend = npend_out;
         o.lav_valid = la > 0 ? 1 : 0;
         for (int p = 0; p < MAXD; p++) {
             o.pl[p] = p < npend_out ? (p == npend - 1 ? lrow : Din->pl[p]) : -1;
             o.pc[p] = p < npend_out ? (p == npend - 1 ? colx : Din->pc[p]) : 0;
-            int fm = 0;
-            for (int wv = 0; wv < T / 64; wv++) fm |= (sh_fast[p][wv] != 0 ? 1 : 0) << wv;
-            o.fast[p] = p < npend_out ? fm : 0;
         }
         *Dout = o;
     }
@@ -585,7 +482,7 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
 // (the same arithmetic as the sweep: :14-25 for a row that was a pivot row, :31-36 otherwise).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void dshard_select_kernel(Desc d, int parity, double *send) {
-    constexpr int MAXD = 8;
+    constexpr int MAXD = DSHARD_MAXD;
     __shared__ double sk[2][16];
     __shared__ int si[2][16];
     __shared__ double sh_coef[2][MAXD], sh_patch[2][MAXD];

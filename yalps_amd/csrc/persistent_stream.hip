@@ -20,8 +20,12 @@ namespace {
 PersistentTable yalps_stream_table() {
     static const PersistentEntry kStream[] = {
     SVARIANT(256, 1, false), SVARIANT(256, 2, false), SVARIANT(1024, 1, false), SVARIANT(1024, 2, false), SVARIANT(1024, 4, false),
-    // (<1024,8> needs 77 VGPR + 118 SGPR spills at the 128-register cap and computed garbage on the GPU: rows wider
-    // than 8193 columns stay with wide_kernel)
+    // (<1024,8> needs 77 VGPR + 118 SGPR spills at the 128-register cap and computed garbage on the GPU in round 1: rows
+    // wider than 8193 columns take sweep_kernel / stream3_kernel.  -DYALPS_EXPERIMENT_STREAM8 builds it for the experiment of
+    // DESIGN.md 4.8 -- tools/build_variant.sh stream8 -DYALPS_EXPERIMENT_STREAM8 stream --, never in the shipped library.)
+#ifdef YALPS_EXPERIMENT_STREAM8
+    SVARIANT(1024, 8, false),
+#endif
 };
     return {kStream, (int)(sizeof kStream / sizeof kStream[0])};
 }

@@ -15,6 +15,7 @@ namespace {
 
 #include "resident_kernel.cuh" // (the sc1 load / store helpers)
 #include "sweep_kernel.cuh" // (the buffer-descriptor row accessors)
+#include "panel_flush.cuh"
 #include "stream3_kernel.cuh"
 // (R = 1: non-temporal row traffic, for tableaux beyond the Infinity Cache)
 #define S3VARIANT(T, J, NT) {T, J, NT, reinterpret_cast<const void *>(&stream3_kernel<T, J, NT != 0>)}

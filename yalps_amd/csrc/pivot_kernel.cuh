@@ -230,7 +230,15 @@ __global__ __launch_bounds__(T) void pivot_kernel(Desc d, int parity, int mode, 
                             pivots_in);
             return;
         }
-        if (C->check_cycles) { // :98,137 (DECIDE launches only: one workgroup)
+        if (C->check_cycles && mode == MODE_SHARD) { // :98,137: shard_cycle_kernel has run the detector on this very pivot
+            hist_len += 1;
+            if (d.cyc_verdict[parity & 1]) {
+                apply_swap();
+                if (b == 0 && tid == 0)
+                    write_state(YALPS_CYCLED, phase, 0, la_in, pbuf, mbuf, 0, 0, 0, 0, 0, 0, 0, hist_len, iter, NAN, pivots_in);
+                return;
+            }
+        } else if (C->check_cycles) { // :98,137 (DECIDE launches only: one workgroup)
             if (hist_len >= C->hist_cap) { // history full: the host grows it; nothing is consumed
                 apply_swap();
                 if (tid == 0)
@@ -489,7 +497,8 @@ __global__ __launch_bounds__(T) void pivot_kernel(Desc d, int parity, int mode, 
     if (b == 0 && tid == 0 && !(force & 1)) {
         const bool counted = have_pivot && mode != MODE_APPLY; // DECIDE already counted an APPLY's pivot
         write_state(RUNNING, phase, 0, la, pbuf ^ 1, mbuf ^ 1, 0, 0, 0, 0, have_pivot ? 1 : 0, row, col,
-                    (mode != MODE_APPLY && phase_switched) ? 0 : hist_len_in, counted ? iter + 1.0 : iter, NAN,
+                    ((mode != MODE_APPLY && phase_switched) ? 0 : hist_len_in) + (mode == MODE_SHARD && have_pivot && C->check_cycles ? 1 : 0),
+                    counted ? iter + 1.0 : iter, NAN,
                     counted ? pivots_in + 1 : pivots_in);
     }
 }

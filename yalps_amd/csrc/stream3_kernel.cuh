@@ -8,7 +8,8 @@
 // gets all pending eliminations in registers (bit for bit what that many sweeps leave) -- for rows of 8194 .. 16385
 // columns (BASELINE config 5), where neither a lane's 16 units of the objective replica nor two normalised pivot rows of
 // 131 KB fit where stream2_kernel keeps them.  Placement:
-//   * the objective replica lives in LDS (2 T J doubles: every lane reads and writes the columns it also holds of a row);
+//   * the objective replica lives in registers (2 J doubles per lane: the columns the lane also holds of a row; round 2 kept
+//     it in LDS, which the sweep's panels of pending rows need now -- panel_flush.cuh -- and the sweep no longer needs the registers);
 //   * the pending normalised pivot rows live in a scratch in global memory shared by the workgroups of an XCD (d.pend: [8 XCDs]
 //     [2 sets][depth][pitch], <= 2 MB per XCD: resident in its L2): written when the pivot is decided (plain stores, by the lane that will
 //     read them during the sweep; every workgroup stores the same bytes), read 16 bytes per lane, unit and pending pivot per
@@ -22,7 +23,8 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
     __shared__ double sh_q, sh_c0; // quotient; objective-row entry of the pivot column
     __shared__ int sh_fail, sh_nt, sh_flag, sh_verdict;
     __shared__ double sh_rowrhs;
-    constexpr int MAXD = 8;
+    constexpr int MAXD = STREAM3_MAXD;
+    constexpr int PU = STREAM3_PANEL_UNITS; // 16-byte units of a row per LDS panel of the sweep (panel_flush.cuh)
     // TWO: the exchange in two steps -- every workgroup publishes its candidate's KEY only; the workgroup that owns the winner
     // then publishes that one row (pending pivots applied) behind a second record.  One more hand-off on the pivot's chain,
     // but 1 row instead of 256 goes through the pending pivots and the L2s per pivot (at 16 units per lane that was 335 MB of
@@ -36,7 +38,7 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
     __shared__ int sh_fast[MAXD][T / 64];       // per wave: nothing of its slice of that pivot row was flushed (:31 select-free path)
     constexpr int JC = J > 8 ? 8 : J; // units per lane that pass through registers at a time (a pivot row being decided)
     constexpr int JA = J > 8 ? 8 : J; // ... of a pending pivot row while it is applied to the rows in flight
-    extern __shared__ __attribute__((aligned(16))) double sm_dyn[]; // olds[2 T J] (objective replica), colv[depth][rpw], nqv[depth][rpw], lav[rpw], rhsv[rpw], tlist[rpw] (int)
+    extern __shared__ __attribute__((aligned(16))) double sm_dyn[]; // colv[depth][rpw], nqv[depth][rpw], lav[rpw], rhsv[rpw], tlist[rpw] (int), panel[depth][2 PU]
 
     const int tid = threadIdx.x, NB = d.nb, b = blockIdx.x;
     const YState *Sin = d.st + parity;
@@ -59,9 +61,10 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
     const int rpw = (d.hcap + NB - 1) / NB;
     const int my_rows = b < h ? (h - 1 - b) / NB + 1 : 0;
     const int depth = d.delay_depth < 1 ? 1 : d.delay_depth > MAXD ? MAXD : d.delay_depth;
-    double *olds = sm_dyn, *colv0 = olds + 2 * T * J, *nqv0 = colv0 + (size_t)depth * rpw, *lav = nqv0 + (size_t)depth * rpw,
+    double *colv0 = sm_dyn, *nqv0 = colv0 + (size_t)depth * rpw, *lav = nqv0 + (size_t)depth * rpw,
            *rhsv = lav + rpw; // (nqv: what replaces a row's pivot-column entry, :25 / :36 -- one division per row and pivot, by one lane)
     int *tlist = reinterpret_cast<int *>(rhsv + rpw);
+    double *panel = rhsv + rpw + (rpw + 3) / 4 * 2; // (behind tlist, 16-byte aligned)
     const double flushed = __longlong_as_double((long long)FLUSHED);
     // The pending normalised pivot rows: one scratch PER XCD (d.pend: [8 XCDs][2 sets][depth][pitch]).  Every workgroup computes the
     // same rows from the same published bytes; the workgroups of one XCD store them to the same place (identical values;
@@ -97,8 +100,9 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
             if (2 * (tid + j * T) + k >= (CHECK ? pitch : n)) padmask |= 1u << (2 * j + k); // (CHECK: see the padding note at the end of the pivot loop)
     constexpr unsigned FULL = J == 16 ? 0xFFFFFFFFu : (1u << (2 * (J & 15))) - 1u;
     // ---- my replica of the objective row (registers), my rows' RHS (LDS) ----
+    double2 ob[J]; // my replica of the objective row: units tid, tid + T, ...
 #pragma unroll
-    for (int j = 0; j < J; j++) *reinterpret_cast<double2 *>(olds + 2 * (tid + j * T)) = row_ld16<AUX_PLAIN>(rsrc_of(mat), lane_off + 16 * T * j, 0);
+    for (int j = 0; j < J; j++) ob[j] = row_ld16<AUX_PLAIN>(rsrc_of(mat), lane_off + 16 * T * j, 0);
     for (int i = tid; i < my_rows; i += T) rhsv[i] = rhs[b + NB * i];
     if (tid == 0) sh_fail = 0;
     __syncthreads();
@@ -127,20 +131,25 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
         for (int i = t0; i < my_rows; i += T) {
             // (the entry and the pending pivot rows' entries of that column: all loads in flight at once -- one after the
             // other they were a dependent trip through L2 per pending pivot on every pivot's chain)
-            double pe[MAXD];
             double v = __hip_atomic_load(mat + (size_t)(b + NB * i) * pitch + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll 1
+            for (int p0 = 0; p0 < npend; p0 += 8) { // (eight pending pivots' entries in flight at a time: registers)
+                double pe[8];
 #pragma unroll
-            for (int p = 0; p < MAXD; p++)
-                pe[p] = p < npend ? __hip_atomic_load(prow0 + (size_t)p * pitch + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+                for (int p = 0; p < 8; p++)
+                    pe[p] = p0 + p < npend ? __hip_atomic_load(prow0 + (size_t)(p0 + p) * pitch + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
 #pragma unroll
-            for (int p = 0; p < MAXD; p++)
-                if (p < npend) v = after1(pe[p], colv0 + p * rpw, nqv0 + p * rpw, sh_pl[p], sh_pc[p], i, v, c);
+                for (int p = 0; p < 8; p++)
+                    if (p0 + p < npend) v = after1(pe[p], colv0 + (p0 + p) * rpw, nqv0 + (p0 + p) * rpw, sh_pl[p0 + p], sh_pc[p0 + p], i, v, c);
+            }
             out[i] = v;
         }
         __syncthreads();
     };
     // the pending pivots applied to (up to) RB half-rows held in registers: units [u0, u0 + JH) of my row slots ri[0 .. cnt)
-    constexpr int JH = J > 8 ? 8 : J, RB = J > 8 ? 2 : 3;
+    // (round 3: only the candidate / winner's row that is about to be published goes this way -- one row, JH units of it per lane at
+    // a time, the pending rows read from my XCD's scratch; the sweep of all rows is panel_flush.cuh)
+    constexpr int JH = J > 8 ? 8 : J, RB = 1;
     auto apply_batch = [&](int u0, double2 (&xb)[RB][JH], const int (&ri)[RB], int cnt) __attribute__((always_inline)) {
 #pragma unroll 1
         for (int p = 0; p < npend; p++) { // (a run-time loop: its scalars are read once per batch of RB half-rows)
@@ -199,50 +208,24 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
     // every touched row streamed once, all pending eliminations in registers; afterwards nothing is pending
     auto flush_pending = [&]() __attribute__((always_inline)) {
         if (npend == 0) return; // (uniform)
-        if (tid < 64) { // compact list of my touched rows (wave 0)
+        int tl = tid;
+        asm volatile("" : "+v"(tl)); // (opaque: the lane masks below are not kept across the pivot loop)
+        if (tl < 64) { // compact list of my touched rows (wave 0)
             int cnt = 0;
             for (int base = 0; base < my_rows; base += 64) {
-                const int i = base + tid;
+                const int i = base + tl;
                 bool t = false;
                 if (i < my_rows)
                     for (int p = 0; p < npend; p++) t = t || i == sh_pl[p] || fabs(colv0[p * rpw + i]) > 1e-16;
                 const unsigned long long m = __ballot(t);
-                if (t) tlist[cnt + __popcll(m & ((1ull << tid) - 1ull))] = i;
+                if (t) tlist[cnt + __popcll(m & ((1ull << tl) - 1ull))] = i;
                 cnt += __popcll(m);
             }
-            if (tid == 0) sh_nt = cnt;
+            if (tl == 0) sh_nt = cnt;
         }
         __syncthreads();
-        const int nt = sh_nt;
-        // The rows in column halves (JH units per lane), RB rows at a time: a chunk of a pending pivot row is read ONCE from my
-        // scratch (L2) and applied to the RB half-rows in registers.  (Row by row the scratch reads were as many bytes per
-        // pending pivot as the rows' own HBM traffic: 2 GB of L2 reads per pivot at 16385 x 16385, ~250 us of a 480 us pivot.)
-#pragma unroll 1
-        for (int u0 = 0; u0 < J; u0 += JH) {
-#pragma unroll 1
-            for (int k = 0; k < nt; k += RB) {
-                double2 xb[RB][JH];
-                int ri[RB];
-#pragma unroll
-                for (int u = 0; u < RB; u++) {
-                    ri[u] = tlist[k + u < nt ? k + u : k];
-                    const __amdgpu_buffer_rsrc_t rs = rsrc_of(mat + (size_t)(b + NB * ri[u]) * pitch);
-                    if (k + u < nt) {
-#pragma unroll
-                        for (int j = 0; j < JH; j++) xb[u][j] = row_ld16<NT ? AUX_NT : AUX_PLAIN>(rs, lane_off + 16 * T * (u0 + j), 0);
-                    }
-                }
-                apply_batch(u0, xb, ri, nt - k);
-#pragma unroll
-                for (int u = 0; u < RB; u++) {
-                    if (k + u < nt) {
-                        const __amdgpu_buffer_rsrc_t rs = rsrc_of(mat + (size_t)(b + NB * ri[u]) * pitch);
-#pragma unroll
-                        for (int j = 0; j < JH; j++) row_st16<NT ? AUX_NT : AUX_PLAIN>(rs, lane_off + 16 * T * (u0 + j), 0, xb[u][j]);
-                    }
-                }
-            }
-        }
+        // (panel_flush.cuh: the pending rows staged in LDS one 1024-column panel at a time, four rows in flight per lane)
+        panel_flush<T, PU, 4, NT>(mat, pitch, b, NB, prow0, npend, colv0, nqv0, rpw, sh_pl, sh_pc, tlist, sh_nt, panel, rsrc_of);
         npend = 0;
         pset ^= 1;
         prow0 = pend_xcd + (size_t)pset * depth * pitch;
@@ -253,12 +236,14 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
     int la = 0; // entering column of the NEXT pivot (phase 2), priced on my objective replica
     auto price = [&]() __attribute__((always_inline)) { // src/simplex.ts:71-79
         KI best = {INFINITY, INT_MAX};
+        int tp = tid;
+        asm volatile("" : "+v"(tp)); // (opaque: the 2 J column numbers of a lane are recomputed here, not kept across the pivot loop)
 #pragma unroll
         for (int j = 0; j < J; j++) {
-            const int c0 = 2 * (tid + j * T);
+            const int c0 = 2 * (tp + j * T);
 #pragma unroll
             for (int k = 0; k < 2; k++) {
-                const double ov = olds[c0 + k];
+                const double ov = elem(ob[j], k);
                 if (c0 + k < n && ov > precision && ki_better(-ov, c0 + k + 1, best.k, best.i)) {
                     best.k = -ov;
                     best.i = c0 + k + 1;
@@ -267,7 +252,7 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
         }
         best = block_argmin<T>(best, sk, si, slot);
         slot ^= 1;
-        la = best.i == INT_MAX ? 0 : best.i;
+        la = __builtin_amdgcn_readfirstlane(best.i == INT_MAX ? 0 : best.i); // (uniform: kept in a scalar register)
     };
     // my candidate of the given kind (1 = most negative RHS, 2 = min ratio against lav[]); uniform result
     auto candidate = [&](int kind) __attribute__((always_inline)) {
@@ -409,7 +394,7 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
             }
             continue;
         }
-        const int row_in = c.i, row = (unsigned)row_in < (unsigned)h ? row_in : 0, owner = row % NB;
+        const int row_in = __builtin_amdgcn_readfirstlane(c.i), row = (unsigned)row_in < (unsigned)h ? row_in : 0, owner = row % NB; // (uniform: scalar registers)
         if (row != row_in && tid == 0) __hip_atomic_store(d.rc_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (never expected)
         const int lslot = owner == b ? row / NB : -1; // my slot of the pivot row, if I own it
         // ---------------- the winner's row as published: the tableau's row after every earlier pivot ----------------
@@ -451,6 +436,8 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
         int col = la;
         if (phase == 1) { // :123-134, JC units of the raw row per lane at a time
             KI e = {INFINITY, INT_MAX};
+            int tp = tid;
+            asm volatile("" : "+v"(tp)); // (opaque: see price())
 #pragma unroll
             for (int jb = 0; jb < J; jb += JC) {
                 double2 pv[JC];
@@ -458,12 +445,12 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
                 for (int j = 0; j < JC; j++) pv[j] = row_ld16<AUX_SC1>(rsrc_src, lane_off + 16 * T * (jb + j), 0);
 #pragma unroll
                 for (int j = 0; j < JC; j++) {
-                    const int c0 = 2 * (tid + (jb + j) * T);
+                    const int c0 = 2 * (tp + (jb + j) * T);
 #pragma unroll
                     for (int k = 0; k < 2; k++) {
                         const double coefficient = elem(pv[j], k);
                         if (c0 + k < n && coefficient < -precision) {
-                            const double ratio = -olds[c0 + k] / coefficient;
+                            const double ratio = -elem(ob[jb + j], k) / coefficient;
                             if (ratio > -INFINITY && ki_better(-ratio, c0 + k + 1, e.k, e.i)) {
                                 e.k = -ratio;
                                 e.i = c0 + k + 1;
@@ -479,7 +466,7 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
                 stop = true;
                 continue;
             }
-            col = e.i;
+            col = __builtin_amdgcn_readfirstlane(e.i);
         }
         if constexpr (CHECK) { // :98,137 hasCycle before the pivot: workgroup 0 (it maintains the basis) decides for everybody
             int cycled = 0;
@@ -530,8 +517,20 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
         } else {
             column_now(colx, colvN);
         }
-        const double q = ld_sc1(src + colx), coef0 = olds[colx], inv_q = 1.0 / q;
-        __syncthreads(); // (everybody has read olds[colx] before its owner patches it below)
+        // the objective row's entry of the pivot column, from the lane that holds it (per-lane predicates over compile-time
+        // (j, e): a select chain over a run-time unit index is turned into a dynamically indexed scratch array by hipcc)
+        {
+            int tc = tid;
+            asm volatile("" : "+v"(tc));
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                if (2 * (tc + j * T) == colx) sh_c0 = ob[j].x;
+                if (2 * (tc + j * T) + 1 == colx) sh_c0 = ob[j].y;
+            }
+        }
+        const double q = ld_sc1(src + colx), inv_q = 1.0 / q;
+        __syncthreads(); // (sh_c0; nobody writes it again before the barriers of the next pivot)
+        const double coef0 = sh_c0;
         YSTAMP(3); // my rows' pivot-column entries, quotient (two barriers)
         const bool nz_rhs = fabs(rhs_row) > 1e-16;
         const double pn_rhs = nz_rhs ? rhs_row / q : 0.0;
@@ -553,6 +552,8 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
         const __amdgpu_buffer_rsrc_t rsrc_new = rsrc_of(prowN);
         unsigned nzmask = 0;
         KI best = {INFINITY, INT_MAX};
+        int tp = tid;
+        asm volatile("" : "+v"(tp)); // (opaque: see price())
 #pragma unroll
         for (int jb = 0; jb < J; jb += JC) {
             double2 pv[JC];
@@ -560,8 +561,8 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
             for (int j = 0; j < JC; j++) pv[j] = row_ld16<AUX_SC1>(rsrc_src, lane_off + 16 * T * (jb + j), 0);
 #pragma unroll
             for (int j = 0; j < JC; j++) {
-                const int c0 = 2 * (tid + (jb + j) * T);
-                double2 pn, ov = *reinterpret_cast<const double2 *>(olds + c0);
+                const int c0 = 2 * (tp + (jb + j) * T);
+                double2 pn, ov = ob[jb + j];
                 bool nzk[2];
 #pragma unroll
                 for (int k = 0; k < 2; k++) {
@@ -585,9 +586,10 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
                         best.i = c0 + k + 1;
                     }
                 }
-                *reinterpret_cast<double2 *>(olds + c0) = ov;
+                ob[jb + j] = ov;
                 row_st16<AUX_PLAIN>(rsrc_new, lane_off + 16 * T * (jb + j), 0, pn);
             }
+            __builtin_amdgcn_sched_barrier(0); // (the next JC units' loads stay behind this group's arithmetic: registers)
         }
         {
             const bool fast = __builtin_amdgcn_ballot_w64(((nzmask | padmask) & FULL) != FULL) == 0; // (per wave)
@@ -605,7 +607,7 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
         done += 1;
         best = block_argmin<T>(best, sk, si, slot); // la of the next pivot (its barrier also publishes the scratch row / rhsv / the pending scalars)
         slot ^= 1;
-        la = best.i == INT_MAX ? 0 : best.i;
+        la = __builtin_amdgcn_readfirstlane(best.i == INT_MAX ? 0 : best.i); // (uniform: kept in a scalar register)
         check();
         YSTAMP(6); // arg-max of the pricing (barriers)
         if (!stop) {

@@ -229,6 +229,12 @@ __global__ __launch_bounds__(T) void wide_kernel(Desc d, int parity, int mode, i
                             pivots_in);
             return;
         }
+        if (mode == MODE_SHARD && C->check_cycles && d.cyc_verdict[parity & 1]) { // :98,137: shard_cycle_kernel's verdict on this pivot
+            apply_swap();
+            if (b == 0 && tid == 0)
+                write_state(YALPS_CYCLED, phase, la_in, pbuf, mbuf, 0, 0, 0, (phase_switched ? 0 : hist_len_in) + 1, iter, NAN, pivots_in);
+            return;
+        }
         have_pivot = true;
     } else if (mode == MODE_APPLY && Sin->dec_valid) {
         row = Sin->dec_row;
@@ -452,7 +458,8 @@ __global__ __launch_bounds__(T) void wide_kernel(Desc d, int parity, int mode, i
     if (b == 0 && tid == 0 && !(force & 1)) {
         const bool counted = have_pivot && mode != MODE_APPLY;
         write_state(RUNNING, phase, la, pbuf ^ 1, INPL ? mbuf : mbuf ^ 1, have_pivot ? 1 : 0, row, col,
-                    (mode != MODE_APPLY && phase_switched) ? 0 : hist_len_in, counted ? iter + 1.0 : iter, NAN,
+                    ((mode != MODE_APPLY && phase_switched) ? 0 : hist_len_in) + (mode == MODE_SHARD && have_pivot && C->check_cycles ? 1 : 0),
+                    counted ? iter + 1.0 : iter, NAN,
                     counted ? pivots_in + 1 : pivots_in);
     }
 }

@@ -146,6 +146,8 @@ const std::vector<RVariant> kStream3 = variants_of({yalps_stream3_table()});
 const std::vector<RVariant> kStream3Check = variants_of({yalps_stream3_check_table()});
 const std::vector<RVariant> kDshard = variants_of({yalps_dshard_table()}); // (launch-per-pivot: (Desc, parity, mode, force, gather); R = non-temporal row traffic)
 constexpr size_t SWEEP_BEYOND_CACHE = 200u << 20; // tableau bytes from which row traffic goes non-temporal (Infinity Cache: 256 MiB)
+constexpr int STREAM3_DEFAULT_DEPTH_WIDE = 8; // pending pivots of stream3_kernel for rows of 4098+ columns with 8+ rows per workgroup (YALPS_HIP_DELAY_DEPTH)
+constexpr int DSHARD_DEFAULT_DEPTH = 8; // pending pivots of a row shard (YALPS_HIP_DELAY_DEPTH, at most DSHARD_MAXD = 16)
 constexpr int RESIDENT_CHUNK = 4096; // pivots per launch of the resident kernel (bounds its run time)
 
 struct YalpsNcclId { // ncclUniqueId (rccl.h: 128 opaque bytes, passed by value)
@@ -357,6 +359,8 @@ struct yalps_tableau {
     int dJ = 0, dnt = 0;
     size_t dshmem = 0;
     void *dsh_block = nullptr;      // ... its arrays, one allocation
+    int32_t *cyc_block = nullptr;   // row shard: shard_cycle_kernel's verdict words (Desc::cyc_verdict)
+    bool shard_check = false;       // ... the running sharded solve has checkCycles on (yalps_shard_begin)
     KernelFn wfn_inplace = nullptr; // row shard: wide_kernel<.., true, nt> for the MODE_SHARD launches (in place; d.obj holds the objective replicas)
     KernelFn wfn = nullptr; // wide_kernel variant used for FUSED / APPLY / SHARD launches when the tableau is
                             // too wide or too tall for pivot_kernel's register-resident batches
@@ -399,6 +403,8 @@ void launch_one(yalps_tableau *t, int parity, int mode, int force, const double 
 // the elimination step of a row shard (MODE_SHARD): in place where the shard has the kernel for it
 void launch_shard(yalps_tableau *t, const double *gathered) {
     const int force = t->ctx->nt_stores ? 64 : 0;
+    if (t->shard_check) // checkCycles: the detector's verdict on the pivot this step is about to decide (shard_kernels.cuh)
+        shard_cycle_kernel<<<dim3(1), dim3(1024), 0, t->ctx->stream>>>(t->d, t->shard_parity, gathered, (t->dfn || t->wfn_inplace) ? 1 : 0);
     if (t->dfn)
         t->dfn<<<dim3(t->nb), dim3(512), t->dshmem, t->ctx->stream>>>(t->d, t->shard_parity, MODE_SHARD, force, gathered);
     else if (t->wfn_inplace)
@@ -806,9 +812,16 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
             // (with the two-step exchange of the 8- and 16-unit forms only the winner's row gets them applied: 2049 x 16385 at
             // depth 4 / 6 / 8: 48.1 / 46.2 / 44.8 us per pivot, 4097 x 8193 40.6 / 36.7 / 35.1, 4097 x 16385 73.8 / 64.5 / 60.5,
             // 1025 x 16385 31.6 / 31.4 / 32.3)
-            const int depth_default = sJ >= 8 ? (rows_per_block >= 8 ? 8 : 6) : std::max(4, (rows_per_block + 1) / 3);
-            const int depth3 = std::min(8, std::max(2, env_int("YALPS_HIP_DELAY_DEPTH", depth_default)));
-            const size_t lds3 = sizeof(double) * (2 * 512 * (size_t)sJ + (2 * (size_t)depth3 + 2) * (size_t)rows_per_block) + sizeof(int32_t) * (size_t)rows_per_block;
+            // (round 3: the sweep stages the pending rows in LDS one 1024-column panel at a time -- panel_flush.cuh -- and the objective
+            // replica moved to registers: up to STREAM3_MAXD = 16 pending pivots, the deepest form whose scalars + panel fit in LDS)
+            const int depth_default = sJ >= 8 ? (rows_per_block >= 8 ? STREAM3_DEFAULT_DEPTH_WIDE : 6) : std::max(4, (rows_per_block + 1) / 3);
+            int depth3 = std::min(STREAM3_MAXD, std::max(2, env_int("YALPS_HIP_DELAY_DEPTH", std::min(depth_default, STREAM3_MAXD))));
+            auto lds3_of = [&](int dep) {
+                return sizeof(double) * (2 * (size_t)dep + 2) * (size_t)rows_per_block + sizeof(int32_t) * (((size_t)rows_per_block + 3) / 4 * 4) +
+                       sizeof(double) * (size_t)dep * 2 * STREAM3_PANEL_UNITS;
+            };
+            while (depth3 > 2 && lds3_of(depth3) > 150 * 1024) depth3--;
+            const size_t lds3 = lds3_of(depth3);
             if (lds3 <= 150 * 1024)
                 for (const RVariant &v : kStream3)
                     if (v.T == 512 && v.J == sJ && v.R == want_nt2) t->svar2 = v;
@@ -916,7 +929,7 @@ void yalps_tableau_destroy(yalps_tableau *t) {
     void *bufs[] = {d.mat[0], d.mat[1], d.rhs[0], d.rhs[1], t->perm_block ? nullptr : d.pos, t->perm_block ? nullptr : d.var, t->perm_block,
                     t->ctl_block ? nullptr : d.st, t->ctl_block ? nullptr : d.cst, t->ctl_block, d.rc_rows[0], d.rc_rows[1], t->perm_backup,
                     d.rc_key[0], d.rc_key[1], d.gen_prow, d.gen_scal, d.part_ratio[0], d.part_ratio[1], d.part_rhs[0], d.part_rhs[1],
-                    t->hist[0], t->hist[1], t->cells, d.dbg, d.obj[0], d.pend, t->dsh_block};
+                    t->hist[0], t->hist[1], t->cells, d.dbg, d.obj[0], d.pend, t->dsh_block, t->cyc_block};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (t->host_state) (void)hipHostFree(t->host_state);
@@ -947,14 +960,15 @@ int32_t yalps_tableau_info(const yalps_tableau *t, char *buf, int32_t len) {
     else
         std::snprintf(str, sizeof str, "pivot_kernel<%d,%d,%d>", t->var.T, t->var.J, t->var.R);
     std::snprintf(buf, (size_t)len, "streaming=%s workgroups=%d resident=%s inplace=%s giveups=%lld resident_off_for=%d inplace_off_for=%d "
-                  "last_path=%s last_resident_launches=%lld node_fused_runs=%lld lock_giveups=%lld", str,
+                  "last_path=%s last_resident_launches=%lld node_fused_runs=%lld lock_giveups=%lld decide=pivot_kernel<%d,%d,%d>", str,
                   t->nb, res, inp, (long long)t->giveups, t->ctx->resident ? t->ctx->resident_skip : -1,
                   t->ctx->inplace ? t->ctx->inplace_skip : -1,
                   t->last_path == 1 ? "resident" : t->last_path == 2 ? "streaming" : t->last_path == 3 ? "resident+streaming"
                   : t->last_path == 4 ? "small" : t->last_path == 8 ? "inplace" : t->last_path == 10 ? "inplace+streaming"
                   : t->last_path == 9 ? "resident+inplace" : t->last_path == 11 ? "resident+inplace+streaming"
                   : t->last_path == 16 ? "generic" : "none",
-                  (long long)(t->last_path & 9 ? t->last_launches : 0), (long long)t->node_fused_runs, (long long)t->ctx->lock_giveups);
+                  (long long)(t->last_path & 9 ? t->last_launches : 0), (long long)t->node_fused_runs, (long long)t->ctx->lock_giveups,
+                  t->var.T, t->var.J, t->var.R); // (decide: the single-workgroup DECIDE launches of checkCycles on the launch-per-pivot path)
     return 0;
 }
 
@@ -1868,9 +1882,16 @@ int32_t yalps_tableau_set_shard(yalps_tableau *t, int32_t rank, int32_t nranks, 
         if (t->wfn_inplace && dJ && env_int("YALPS_HIP_SHARD_DELAY", 1) && rows_per_block >= env_int("YALPS_HIP_DELAY_MIN_ROWS", 4)) {
             // (measured, us per pivot at depth 2 / 4 / 6 / 8: 2049 x 16385 73 / 53 / 48 / 46, 8193 x 16385 207 / 125 / 105 / 97:
             // a launch-per-pivot step has a larger fixed part than stream3_kernel's, the deepest form wins everywhere)
-            const int depth = std::min(8, std::max(2, env_int("YALPS_HIP_DELAY_DEPTH", 8)));
+            // round 3: the sweep stages the pending rows in LDS one 1024-column panel at a time (panel_flush.cuh) -- up to 16
+            // pending pivots; the deepest form whose scalars + panel fit the LDS of a CU
+            int depth = std::min(DSHARD_MAXD, std::max(2, env_int("YALPS_HIP_DELAY_DEPTH", DSHARD_DEFAULT_DEPTH)));
+            auto lds_of = [&](int dep) {
+                return sizeof(double) * (2 * (size_t)dep + 2) * (size_t)rows_per_block + sizeof(int32_t) * (((size_t)rows_per_block + 3) / 4 * 4) +
+                       sizeof(double) * (size_t)dep * 2 * DSHARD_PANEL_UNITS;
+            };
+            while (depth > 2 && lds_of(depth) > 150 * 1024) depth--;
             const bool nt = env_int("YALPS_HIP_SHARD_NT", sizeof(double) * (size_t)d.pitch * (size_t)t->height > SWEEP_BEYOND_CACHE ? 1 : 0) != 0;
-            const size_t lds = sizeof(double) * (2 * (size_t)depth + 2) * (size_t)rows_per_block + sizeof(int32_t) * (size_t)rows_per_block;
+            const size_t lds = lds_of(depth);
             if (lds <= 150 * 1024)
                 for (const RVariant &v : kDshard)
                     if (v.T == 512 && v.J == dJ && v.R == (nt ? 1 : 0)) t->dfn = reinterpret_cast<KernelFn>(v.fn);
@@ -1895,6 +1916,11 @@ int32_t yalps_tableau_set_shard(yalps_tableau *t, int32_t rank, int32_t nranks, 
             }
         }
     }
+    if (!t->cyc_block) {
+        HIP_TRY(hipMalloc(&t->cyc_block, 16));
+        HIP_TRY(hipMemsetAsync(t->cyc_block, 0, 16, s));
+    }
+    d.cyc_verdict = t->cyc_block;
     // graphs captured for the unsharded tableau hold the old Desc
     for (int k = 0; k < 2; k++) {
         if (t->graph_exec[k]) (void)hipGraphExecDestroy(t->graph_exec[k]);
@@ -1907,10 +1933,32 @@ int32_t yalps_tableau_set_shard(yalps_tableau *t, int32_t rank, int32_t nranks, 
 
 int64_t yalps_shard_slot_doubles(const yalps_tableau *t) { return t ? SHARD_HDR + 2 * (int64_t)t->d.pitch : 0; }
 
-int32_t yalps_shard_begin(yalps_tableau *t, double precision, double maxPivots) {
+// checkCycles: how many pivots the history has room for beyond what the last status poll saw (the history is grown by
+// yalps_shard_poll / between the batches of yalps_shard_run, where the host knows the count: poll at least this often)
+constexpr int64_t SHARD_HIST_MARGIN = 8192;
+
+static int shard_hist_reserve(yalps_tableau *t, int64_t have) {
+    if (!t->shard_check || have + SHARD_HIST_MARGIN <= t->hist_cap) return 0;
+    HIP_TRY(hipStreamSynchronize(t->ctx->stream));
+    if (int rc = grow_history(t, have + 2 * SHARD_HIST_MARGIN, have)) return rc;
+    YConst hc;
+    HIP_TRY(hipMemcpy(&hc, t->d.cst, sizeof(YConst), hipMemcpyDeviceToHost));
+    hc.hist_cap = t->hist_cap;
+    hc.hist_leaving = t->hist[0];
+    hc.hist_entering = t->hist[1];
+    HIP_TRY(hipMemcpy(t->d.cst, &hc, sizeof(YConst), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int32_t yalps_shard_begin(yalps_tableau *t, double precision, double maxPivots, int32_t checkCycles) {
     if (!t || t->height < 1) return fail(YALPS_E_ARG, "yalps_shard_begin: no tableau uploaded");
+    if (t->d.nshards < 1 || !t->d.cyc_verdict) return fail(YALPS_E_ARG, "yalps_shard_begin: yalps_tableau_set_shard first");
     HIP_TRY(hipSetDevice(t->ctx->device));
-    int rc = init_state(t, precision, maxPivots, 0);
+    if ((checkCycles != 0) != t->shard_check) t->generation = next_tableau_generation(); // (a captured batch has / lacks the detector's launch)
+    t->shard_check = checkCycles != 0;
+    if (t->shard_check && t->hist_cap < SHARD_HIST_MARGIN)
+        if (int rc0 = grow_history(t, SHARD_HIST_MARGIN, 0)) return rc0;
+    int rc = init_state(t, precision, maxPivots, checkCycles);
     if (rc) return rc;
     launch_one(t, 0, MODE_FUSED, 0); // bootstrap scan: emits this rank's first partials
     HIP_TRY(hipGetLastError());
@@ -1957,6 +2005,7 @@ int32_t yalps_shard_poll(yalps_tableau *t, int32_t *status_out, double *result_o
     YState now;
     HIP_TRY(hipMemcpy(&now, t->d.st + t->shard_parity, sizeof(YState), hipMemcpyDeviceToHost));
     if (now.status != RUNNING) t->cur = now.mbuf;
+    else if (int rc = shard_hist_reserve(t, now.hist_len)) return rc;
     if (status_out) *status_out = now.status;
     if (result_out) *result_out = now.result;
     if (pivots_out) *pivots_out = now.pivots;
@@ -2132,7 +2181,7 @@ static int shard_step(yalps_tableau *t, yalps_comm *c, size_t slot) {
     return 0;
 }
 
-int32_t yalps_shard_run(yalps_tableau *t, yalps_comm *c, double precision, double maxPivots, int32_t check_every,
+int32_t yalps_shard_run(yalps_tableau *t, yalps_comm *c, double precision, double maxPivots, int32_t checkCycles, int32_t check_every,
                         int32_t *status_out, double *result_out, int64_t *pivots_out, float *gpu_ms_out) {
     if (!t || !c || t->height < 1 || t->ctx != c->ctx) return fail(YALPS_E_ARG, "yalps_shard_run: bad argument");
     if (t->d.nshards != c->nranks || t->d.shard_rank != c->rank)
@@ -2143,8 +2192,9 @@ int32_t yalps_shard_run(yalps_tableau *t, yalps_comm *c, double precision, doubl
     const size_t slot = (size_t)yalps_shard_slot_doubles(t);
     if (int rc = comm_reserve(c, slot)) return rc;
     if (check_every < 2) check_every = 2;
+    if (check_every > SHARD_HIST_MARGIN / 2) check_every = (int32_t)(SHARD_HIST_MARGIN / 2);
     check_every &= ~1; // (even: the launch parity is back where it started after a batch, so one captured batch serves every replay)
-    if (int rc = yalps_shard_begin(t, precision, maxPivots)) return rc;
+    if (int rc = yalps_shard_begin(t, precision, maxPivots, checkCycles)) return rc;
     if (gpu_ms_out) HIP_TRY(hipEventRecord(ctx->ev0, s));
     // The first batch runs eagerly (RCCL sets its channels up on first use); from the second on the batch is ONE
     // hipGraph replay where the transport can be captured (RCCL's collectives can; the host transport waits per pivot).
@@ -2208,6 +2258,7 @@ int32_t yalps_shard_run(yalps_tableau *t, yalps_comm *c, double precision, doubl
         HIP_TRY(hipStreamSynchronize(s));
         fin = t->host_state[1];
         if (fin.status != RUNNING) break;
+        if (int rc = shard_hist_reserve(t, fin.hist_len)) return rc; // (checkCycles: room for the next batch's pivots)
     }
     if (gpu_ms_out) {
         HIP_TRY(hipEventRecord(ctx->ev1, s));

@@ -62,8 +62,8 @@ class HipShardOps:
         if private_stream:
             torch.cuda.synchronize(device)  # (the buffers were zeroed on torch's stream)
 
-    def begin(self, precision, max_pivots):
-        self.tab.shard_begin(precision, max_pivots)
+    def begin(self, precision, max_pivots, check_cycles=False):
+        self.tab.shard_begin(precision, max_pivots, check_cycles)
 
     def select(self):
         self.tab.shard_select(self.send.data_ptr())
@@ -78,9 +78,9 @@ class HipShardOps:
         m, pos, var = self.tab.download(perm_len=self.perm_len)
         return m, pos, var
 
-    def run_native(self, comm, precision=1e-8, max_pivots=8192.0, check_every=64):
+    def run_native(self, comm, precision=1e-8, max_pivots=8192.0, check_every=64, check_cycles=False):
         """yalps_shard_run: returns (status name, result, n_pivots, gpu_ms)."""
-        st, result, pivots, ms = self.tab.shard_run(comm, precision, max_pivots, check_every)
+        st, result, pivots, ms = self.tab.shard_run(comm, precision, max_pivots, check_every, check_cycles)
         return STATUS[st], result, pivots, ms
 
     def close(self):
@@ -109,9 +109,9 @@ def native_comm(ctx, rank, world, transport="rccl", group=None):
     return _native.Comm.host(ctx, allgather, rank, world)
 
 
-def sharded_simplex_native(ops, comm, precision=1e-8, max_pivots=8192.0, check_every=64):
+def sharded_simplex_native(ops, comm, precision=1e-8, max_pivots=8192.0, check_every=64, check_cycles=False):
     """One row-sharded solve with no Python between two pivots; returns (status, result, n_pivots)."""
-    status, result, pivots, _ = ops.run_native(comm, precision, max_pivots, check_every)
+    status, result, pivots, _ = ops.run_native(comm, precision, max_pivots, check_every, check_cycles)
     return status, result, pivots
 
 
@@ -140,10 +140,11 @@ class TorchComm:
             self.dist.all_gather_into_tensor(recv, send, group=self.group)
 
 
-def sharded_simplex(ops, comm, precision=1e-8, max_pivots=8192.0, check_every=32):
+def sharded_simplex(ops, comm, precision=1e-8, max_pivots=8192.0, check_every=32, check_cycles=False):
     """Drives one row-sharded solve; returns (status, result, n_pivots), identical on every rank.
-    Mirrors the return protocol of the reference's simplex() (src/simplex.ts:66-142)."""
-    ops.begin(precision, max_pivots)
+    Mirrors the return protocol of the reference's simplex() (src/simplex.ts:66-142); check_cycles = options.checkCycles
+    (:98,137): the permutations and the pivot history are replicated, every rank runs hasCycle on the same pivot."""
+    ops.begin(precision, max_pivots, check_cycles)
     while True:
         for _ in range(check_every):
             ops.select()
