@@ -50,7 +50,8 @@ HBM_COPY_GBPS = 6290.0  # what a float4 copy reaches on this chip (same guide: 7
 
 
 def onchip_floor_us(T, J, R, clock_ghz=2.4):
-    """What bounds resident_kernel<T,J,R> per pivot once the tableau sits in the register files: not HBM, but
+    """(The round-2 MODEL of the floor, kept beside the measured one for comparison; `roofline.frac` no longer uses it.)
+    What bounds resident_kernel<T,J,R> per pivot once the tableau sits in the register files: not HBM, but
     (a) the one exchange through the fabric that every pivot needs, priced with the guide's own list
         (MI355X_MICROARCH.md, "Persistent kernels: synchronisation and hand-off price list"):
         handoff-flag, drained sc1 payload + 16-byte flag, idle chip .................. 1.3 us
@@ -78,18 +79,31 @@ def algorithmic_bytes_per_pivot(h, w):
 
 
 def measured_traffic(size, resident, pivots_per_launch):
-    """HBM bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, corrected as
+    """(HBM bytes per launch, the profiles/ file they come from): PMC counters (FETCH_SIZE x2 + WRITE_SIZE, corrected as
     MI355X_MICROARCH.md prescribes), collected in separate rocprofv3 --pmc passes of this same
     workload and committed under profiles/ -- bench.py cannot run the profiler on itself."""
     name = "r02_pmc_traffic_resident.json" if resident else "r01_pmc_traffic.json"
     path = os.path.join(ROOT, "profiles", name)
     if size != 2048 or not os.path.exists(path):
-        return None
+        return None, None
     with open(path) as f:
         rec = json.load(f)
     if resident:
-        return rec["traffic_bytes_per_pivot"] * pivots_per_launch
-    return rec["traffic_bytes_per_launch"]
+        return rec["traffic_bytes_per_pivot"] * pivots_per_launch, "profiles/" + name
+    return rec["traffic_bytes_per_launch"], "profiles/" + name
+
+
+def measured_exchange_floor(native, ctx, nb, T, J, epochs=4000):
+    """The resident kernels' per-pivot exchange and nothing else, measured on this chip in this run
+    (yalps_ctx_exchange_floor, persistent_floor.hip: `nb` workgroups of T lanes, rows of 2 J T doubles): us per round of
+    flag only | flag + dependent fetch of the winner's row | row published write-through + drained, flag, fetch."""
+    units = J if (T, J) in ((512, 2), (512, 3), (256, 1), (256, 2)) else (2 if T == 512 else 1)
+    out = {}
+    for name, variant in (("flags_only_us", 0), ("flags_and_fetch_us", 2), ("publish_flags_fetch_us", 3)):
+        native.exchange_floor(ctx, nb, T, units, 200, variant)  # warm-up
+        out[name] = min(native.exchange_floor(ctx, nb, T, units, epochs, variant) for _ in range(3))
+    out["lanes"], out["units"], out["workgroups"], out["row_bytes"] = T, units, nb, 16 * T * units
+    return out
 
 
 def cpu_baseline(M, N, seed, budget_pivots, threads=1):
@@ -226,16 +240,18 @@ def main():
             us_launch = 1e3 * gpu_ms / (launches * args.steps)
             bytes_launch = bpp * npiv / launches
             ach = bytes_launch / (us_launch * 1e-6) / 1e9
+            traffic, traffic_source = (None, None) if inplace else measured_traffic(args.size, resident, bytes_launch / bpp)
             out["roofline"] = {
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-                "frac_of_copy_rate": ach / HBM_COPY_GBPS,
-                "traffic": None if inplace else measured_traffic(args.size, resident, bytes_launch / bpp),
+                "frac_hbm": ach / HBM_PEAK_GBPS, "frac_of_copy_rate": ach / HBM_COPY_GBPS,
+                "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": info["resident"].split(" ")[0] if resident else info["inplace"] if inplace else info["streaming"],
                 "launches_per_step": launches, "avg_us": us_launch, "bytes_per_launch": bytes_launch,
                 "us_per_pivot": us_pivot,
                 "note": ("persistent kernel: one launch = up to %s pivots with the tableau resident in registers; achieved = "
-                         "algorithmic bytes (SURVEY 8d, 16*h*w per pivot) / HIP-event time, kept as algorithmic_equiv; real HBM "
-                         "traffic is `traffic`; frac = onchip_floor.us / us_per_pivot, the bound that binds this kernel."
+                         "algorithmic bytes (SURVEY 8d, 16*h*w per pivot) / HIP-event time = frac_hbm, kept as algorithmic_equiv; real HBM "
+                         "traffic is `traffic`; the bound that binds this kernel is the exchange through the fabric every pivot needs: "
+                         "bound/achieved/peak/unit/frac are stated against onchip_floor, MEASURED in this run on this chip."
                          % info.get("chunk", "?")) if resident else
                         ("persistent in-place kernel: one launch = many pivots, rows streamed from HBM / Infinity Cache; "
                          "algorithmic bytes (SURVEY 8d) / HIP-event time") if inplace else
@@ -245,14 +261,25 @@ def main():
                 # algorithmic bytes): `frac` is the fraction of the bound that does bind it, the algorithmic figure stays
                 # beside it under its own name
                 T, J, R = (int(x) for x in info["resident"].split("<")[1].split(">")[0].split(",")[:3])
-                floor = onchip_floor_us(T, J, R)
+                model = onchip_floor_us(T, J, R)
+                nb = int(info["workgroups"])
+                meas = measured_exchange_floor(_native, ctx, nb, T, J)
+                floor_us = meas["publish_flags_fetch_us"] + model["valu_critical_us"]
                 rf = out["roofline"]
                 rf["algorithmic_equiv"] = {"achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
                                            "frac_of_copy_rate": ach / HBM_COPY_GBPS,
                                            "note": "what a streaming implementation would have to move / time; not an efficiency"}
-                rf["onchip_floor"] = floor
-                rf["frac"] = floor["us"] / us_pivot
-                rf["bound_detail"] = "on-chip: exchange latency through the fabric + fp64 vector issue (see onchip_floor.model)"
+                rf["onchip_floor"] = {
+                    "us": floor_us, "measured_exchange": meas, "valu_critical_us": model["valu_critical_us"], "model_us_round2": model["us"],
+                    "note": "floor = the exchange every pivot needs, measured in this run by exchange_floor_kernel (%d workgroups x %d lanes: each "
+                            "publishes a %d-byte row write-through + drained, raises a 16-byte record, polls everybody's, fetches the winner's "
+                            "row -- no tableau, no arithmetic) + the fp64 issue time of the three row passes that cannot overlap it"
+                            % (nb, T, meas["row_bytes"])}
+                # the block states ONE bound consistently: pivots/s against the pivots/s of the measured floor
+                rf["bound"], rf["unit"] = "onchip", "pivots/s"
+                rf["achieved"], rf["peak"] = 1e6 / us_pivot, 1e6 / floor_us
+                rf["frac"] = floor_us / us_pivot
+                rf["bound_detail"] = "on-chip: the measured exchange through the fabric + fp64 vector issue (onchip_floor); the HBM figure of SURVEY 8(d) is frac_hbm / algorithmic_equiv"
             if inplace and "delay_depth" in info and info["inplace"].startswith(("stream2_kernel", "stream3_kernel")):
                 # delayed row updates: a row is streamed once per `delay_depth` pivots, so the algorithmic bytes / time
                 # may exceed the HBM peak without being an efficiency; the roofline that binds is the traffic actually moved

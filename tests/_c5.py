@@ -13,9 +13,9 @@ import numpy as np
 M = N = 16384
 W, H = N + 1, M + 1
 SEED = 42
-# Pivot budget per phase (src/simplex.ts:69,109): not a multiple of the delay depth 8 -- 41 full depth-8 flushes, then five
-# pivots pending when the loop stops; with 100 pivots per persistent launch (YALPS_HIP_RESIDENT_CHUNK) three launch
-# boundaries, two of them with pivots pending (100 and 300 are no multiples of 8 either).
+# Pivot budget per phase (src/simplex.ts:69,109): no multiple of the delay depth (16 since round 3: 20 full flushes, then
+# thirteen pivots pending when the loop stops; 41 + 5 at depth 8); with 100 pivots per persistent launch
+# (YALPS_HIP_RESIDENT_CHUNK) three launch boundaries, each of them with pivots pending (100 = 6 * 16 + 4).
 BUDGET = 333
 CHUNK = 100
 BLOCK = 512  # rows per SHA-256 block

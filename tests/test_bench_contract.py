@@ -27,8 +27,13 @@ def test_default_workload_line():
     for k in KEYS + ("cpu_baseline",):
         assert k in rec, k
     assert rec["n_gpus"] == 1 and rec["steps"] == 2 and rec["vs_baseline"] is None and rec["dtype"] == "f64"
-    assert rec["value"] > 0 and rec["roofline"]["bound"] in ("hbm", "mfma") and rec["cpu_baseline"]["value"] > 0
+    assert rec["value"] > 0 and rec["roofline"]["bound"] in ("hbm", "mfma", "onchip") and rec["cpu_baseline"]["value"] > 0
     assert "workload" in rec["config"]
+    rf = rec["roofline"]
+    if rf["bound"] == "onchip":  # the register-resident kernel: one bound stated consistently, the HBM figure beside it
+        assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["unit"] == "pivots/s" and rf["frac_hbm"] > 0
+        floor = rf["onchip_floor"]
+        assert 0 < floor["measured_exchange"]["flags_only_us"] <= floor["measured_exchange"]["publish_flags_fetch_us"] < floor["us"] < 50
 
 
 @pytest.mark.gpu

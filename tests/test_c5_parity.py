@@ -2,7 +2,7 @@
 
 333 pivots per phase (tests/_c5.py: no multiple of the delay depth, 41 full depth-8 flushes, both sets of pending rows,
 three launch boundaries of the persistent loop at 100 pivots per launch) through every kernel that runs this shape --
-stream3_kernel<512,16,nt>, sweep_kernel<512,16,nt>, dshard_kernel<512,16,nt> with one rank over RCCL and with two ranks
+stream3_kernel<512,16,nt>, sweep_kernel<512,16,nt>, dshard_kernel<512,16,nt,panel> with one rank over RCCL and with two ranks
 over the host transport -- each compared with oracle/liboracle_omp.so on the box's host cores: the whole tableau
 (SHA-256 per block of 512 rows), both permutations, column 0, status, result, pivot count.  Two inputs: the LP as
 generated (phase-2 pivots, src/simplex.ts:66-103) and an infeasible start with exact zeros (phase 1, :106-142).
@@ -89,13 +89,13 @@ def _run_workers(kind, world, variant, budget, tmp_path, env_extra=None):
 @pytest.mark.parametrize("kind,world,variant", [("hip-rccl", 1, "phase2"), ("hip-rccl", 1, "phase1"), ("hip-native", 2, "phase2"),
                                                 ("hip-native", 2, "phase1"), ("hip", 2, "phase1")])
 def test_c5_row_shards_against_the_oracle(tmp_path, kind, world, variant):
-    """The row-sharded path with delayed row updates (dshard_kernel<512,16,nt>, depth 8, the library's own loop): one rank
+    """The row-sharded path with delayed row updates (dshard_kernel<512,16,nt,panel>, depth 16, the library's own loop): one rank
     holding all rows over RCCL (ncclAllGather between the kernels, batches of 64 pivots as hipGraph replays), and two ranks
     sharing the test GPU over the host transport (8192 rows each, the candidate rows travel with the pending pivots applied);
     the last case drives the same kernels from the Python loop over gloo (yalps_amd/sharded.py::sharded_simplex)."""
     ref = _c5.reference(variant)
     res = _run_workers(kind, world, variant, _c5.BUDGET, tmp_path)
-    assert str(res["kernel"]).startswith("dshard_kernel<512,16,nt>"), res["kernel"]
+    assert str(res["kernel"]).startswith("dshard_kernel<512,16,nt,panel>"), res["kernel"]
     assert (str(res["status"]), int(res["pivots"])) == (ref["status"], ref["pivots"]) and _same(float(res["result"]), ref["result"])
     assert np.array_equal(res["pos"], ref["pos"]) and np.array_equal(res["var"], ref["var"])
     assert np.array_equal(res["col0"].view(np.int64), ref["ref"][:, 0].view(np.int64))
@@ -120,6 +120,6 @@ def test_c5_whole_solve_record_persistent_kernels(monkeypatch, delay, kernel):
 def test_c5_whole_solve_record_row_shard_one_rank(tmp_path):
     rec = json.load(open(RECORD))["record"]
     res = _run_workers("hip-rccl", 1, "phase2", "inf", tmp_path)
-    assert str(res["kernel"]).startswith("dshard_kernel<512,16,nt>"), res["kernel"]
+    assert str(res["kernel"]).startswith("dshard_kernel<512,16,nt,panel>"), res["kernel"]
     got = record_of(str(res["status"]), float(res["result"]), int(res["pivots"]), res["col0"][0], res["col0"], res["pos"], res["var"])
     assert got == rec

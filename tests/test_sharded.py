@@ -109,10 +109,14 @@ DELAYED = [
     ("hip", 2, 2300, 4200, 6, 150, False, {}, "dshard_kernel<512,6>,delay_depth:8"),
     ("hip-native", 3, 3300, 4200, 5, 131, True, {}, "dshard_kernel<512,6>,delay_depth:8"),
     # round 3: up to 16 pending pivots (the sweep stages them in LDS, panel_flush.cuh); budgets between two sweeps
-    ("hip", 2, 2300, 4200, 6, 150, False, {"YALPS_HIP_DELAY_DEPTH": "16"}, "dshard_kernel<512,6>,delay_depth:16"),
-    ("hip-native", 3, 3300, 4200, 5, 131, True, {"YALPS_HIP_DELAY_DEPTH": "12"}, "dshard_kernel<512,6>,delay_depth:12"),
-    ("hip", 2, 100, 9000, 8, 401, True, {"YALPS_HIP_DELAY_MIN_ROWS": "1", "YALPS_HIP_DELAY_DEPTH": "16"}, "dshard_kernel<512,16>,delay_depth:16"),
-    ("hip-native", 2, 700, 1000, 3, None, False, {"YALPS_HIP_DELAY_MIN_ROWS": "1", "YALPS_HIP_DELAY_DEPTH": "13"}, "dshard_kernel<512,1>,delay_depth:13"),
+    # (the sweep through LDS panels, forced onto small shards -- by default it is taken from 24 rows per workgroup on --, and the
+    # pending rows straight from L2 at depths beyond 8)
+    ("hip", 2, 2300, 4200, 6, 150, False, {"YALPS_HIP_DELAY_DEPTH": "16", "YALPS_HIP_SHARD_PANEL": "1"}, "dshard_kernel<512,6,panel>,delay_depth:16"),
+    ("hip-native", 3, 3300, 4200, 5, 131, True, {"YALPS_HIP_DELAY_DEPTH": "12", "YALPS_HIP_SHARD_PANEL": "1"}, "dshard_kernel<512,6,panel>,delay_depth:12"),
+    ("hip", 2, 100, 9000, 8, 401, True, {"YALPS_HIP_DELAY_MIN_ROWS": "1", "YALPS_HIP_DELAY_DEPTH": "16", "YALPS_HIP_SHARD_PANEL": "1"}, "dshard_kernel<512,16,panel>,delay_depth:16"),
+    ("hip-native", 2, 4700, 1000, 3, 90, False, {"YALPS_HIP_DELAY_DEPTH": "13", "YALPS_HIP_SHARD_PANEL": "1"}, "dshard_kernel<512,1,panel>,delay_depth:13"),
+    ("hip", 2, 2300, 4200, 6, 150, False, {"YALPS_HIP_DELAY_DEPTH": "14"}, "dshard_kernel<512,6>,delay_depth:14"),
+    ("hip-native", 2, 13000, 2100, 7, 45, True, {}, "dshard_kernel<512,4,panel>,delay_depth:16"),  # 26 rows per workgroup: the default
     # ... and the same shard one sweep per pivot, by request
     ("hip", 2, 2300, 4200, 6, 37, False, {"YALPS_HIP_SHARD_DELAY": "0"}, "wide_kernel<1024,4>"),
 ]

@@ -103,8 +103,9 @@ print("ok")
 """
 
 
+@pytest.mark.parametrize("panel", ["0", "1"], ids=["direct", "panel"])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "seed%d-%dx%d" % c[:3])
-def test_sparse_family_through_dshard(monkeypatch, omp_oracle, tmp_path, case):
+def test_sparse_family_through_dshard(monkeypatch, omp_oracle, tmp_path, case, panel):
     """The same tableaux as ONE row shard (rank 0 of 1) through dshard_select_kernel / dshard_kernel<512,16>, depth 8, the
     Python loop with the status polled every 8 pivots: every pending row is stored by one launch and read by later ones --
     the launch boundary dshard_kernel.cuh relies on for its single `d.dpend`.  (In a child process: the candidate slots are
@@ -117,13 +118,13 @@ def test_sparse_family_through_dshard(monkeypatch, omp_oracle, tmp_path, case):
     inp, out = str(tmp_path / "in.npy"), str(tmp_path / "out.npz")
     np.save(inp, m)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, YALPS_HIP_DELAY_DEPTH="8", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, YALPS_HIP_DELAY_DEPTH="8", YALPS_HIP_SHARD_PANEL=panel, HSA_ENABLE_IPC_MODE_LEGACY="0")  # (the sweep through LDS panels and straight from L2)
     run = subprocess.run([sys.executable, "-c", DSHARD_CHILD % dict(root=root, inp=inp, out=out, h=h, w=w, budget=budget)],
                          capture_output=True, text=True, env=env, timeout=600, cwd=root)
     assert run.returncode == 0 and "ok" in run.stdout, run.stdout + run.stderr
     res = np.load(out)
     kernel = str(res["kernel"])
-    assert kernel.startswith("dshard_kernel<512,16") and kernel.endswith("delay_depth:8"), kernel
+    assert kernel.startswith("dshard_kernel<512,16") and kernel.endswith("delay_depth:8") and (",panel" in kernel) == (panel == "1"), kernel
     assert (str(res["status"]), int(res["pivots"])) == (est, epiv) and G.same_number(float(res["result"]), eres), (res["status"], res["pivots"], est, epiv)
     assert np.array_equal(res["pos"], rpos) and np.array_equal(res["var"], rvar)
     assert np.array_equal(res["matrix"].view(np.int64), ref.view(np.int64))

@@ -19,7 +19,7 @@ SYMBOLS = (
     "yalps_last_error", "yalps_device_count", "yalps_simplex_f64", "yalps_simplex_f64_ex", "yalps_ctx_create",
     "yalps_ctx_destroy", "yalps_tableau_create", "yalps_tableau_destroy", "yalps_tableau_upload",
     "yalps_tableau_download", "yalps_tableau_download_rhs", "yalps_tableau_copy", "yalps_tableau_height",
-    "yalps_tableau_solve", "yalps_tableau_pivot", "yalps_tableau_bench_sweep", "yalps_dense_lp_f64", "yalps_dense_lp_rows_f64",
+    "yalps_tableau_solve", "yalps_tableau_pivot", "yalps_tableau_bench_sweep", "yalps_ctx_exchange_floor", "yalps_dense_lp_f64", "yalps_dense_lp_rows_f64",
     "yalps_round_to_precision", "yalps_ctx_create_on_stream", "yalps_tableau_set_shard", "yalps_shard_slot_doubles",
     "yalps_shard_begin", "yalps_shard_select", "yalps_shard_apply", "yalps_shard_poll", "yalps_tableau_info",
     "yalps_tableau_assemble", "yalps_simplex_sparse_f64", "yalps_tableau_apply_cuts", "yalps_tableau_node_solve", "yalps_tableau_download_solution", "yalps_milp_f64", "yalps_batch_create", "yalps_batch_destroy", "yalps_batch_set_root", "yalps_batch_solve", "yalps_batch_download",
@@ -218,6 +218,13 @@ class Context:
         if self.handle:
             lib().yalps_ctx_destroy(self.handle)
             self.handle = C.c_void_p()
+
+
+def exchange_floor(ctx, workgroups=256, lanes=512, units=2, epochs=4000, variant=3):
+    """us per round of the resident kernels' bare exchange on this chip (yalps_ctx_exchange_floor)."""
+    us = C.c_float()
+    check(lib().yalps_ctx_exchange_floor(ctx.handle, workgroups, lanes, units, epochs, variant, C.byref(us)))
+    return us.value
 
 
 class DeviceTableau:

@@ -21,7 +21,7 @@
 // pending rows serves all XCDs here (stream3_kernel needs one per XCD): every workgroup stores the same bytes, reads back
 // within the launch only what it stored itself, and a launch boundary writes the L2s back and invalidates them.
 // ------------------------------------------------------------------------------------------
-template <int T, int J, bool NT>
+template <int T, int J, bool NT, bool PANEL>
 __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mode: MODE_SHARD*/, int /*force*/, const double *gather) {
     __shared__ double sk[2][16];
     __shared__ int si[2][16];
@@ -165,8 +165,11 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
             if (tid == 0) sh_nt = cnt;
         }
         __syncthreads();
-        // (panel_flush.cuh: the pending rows staged in LDS one column panel at a time, four rows in flight per lane)
-        panel_flush<T, PU, 4, NT>(mat, pitch, b, NB, prow0, npend, colv0, nqv0, rpw, sh_pl, sh_pc, tlist, sh_nt, panel, rsrc_of);
+        // (panel_flush.cuh: the pending rows staged in LDS one column panel at a time, a wave per row, eight units per lane, two rows in flight per wave)
+        if constexpr (PANEL)
+            panel_flush<T, PU, 64, 1, NT>(mat, pitch, b, NB, prow0, npend, colv0, nqv0, rpw, sh_pl, sh_pc, tlist, sh_nt, panel, rsrc_of);
+        else // (few rows per workgroup: the pending rows straight from L2, round 2's form)
+            direct_flush<T, J, NT>(mat, pitch, b, NB, prow0, npend, colv0, nqv0, rpw, sh_pl, sh_pc, tlist, sh_nt, rsrc_of);
         npend = 0;
     };
     auto write_state = [&](int status, int phase_, int la_, int pbuf_, int swap_valid_, int swap_row_, int swap_col_, int64_t hist_len_,

@@ -11,7 +11,7 @@
 // rows pass through registers one panel-wide segment at a time: L2 traffic for the pending rows drops to npend x pitch per
 // workgroup and sweep, a pending entry costs one ds_read_b128 per D rows, and a lane holds one unit per row in flight, so
 // the sweep no longer decides the kernel's register budget (tools/micro/panel_sweep.hip, profiles/r03_panel_sweep.txt:
-// D = 4 rows in flight, panels as wide as LDS allows; 16 pending pivots of 1024 columns = 128 KB).
+// panels as wide as LDS allows; 16 pending pivots of 1024 columns = 128 KB; D rows in flight per lane).
 //
 // The arithmetic per element is the reference's, pending pivot by pending pivot, oldest first (src/simplex.ts:14-38):
 //   the row that was pending pivot p's pivot row:  x = p-th normalised row (0.0 where pivot() flushed, :17-24)
@@ -22,14 +22,18 @@
 // were and what replaces them; pl[p] = my slot of pending pivot p's pivot row or -1, pc[p] = its pivot column (mat index);
 // tlist[0 .. nt) = my row slots touched by at least one pending pivot.  Rows and pending rows are addressed through buffer
 // descriptors of one row (rsrc_of): units past the pitch read as 0.0 and their stores are dropped.
-template <int T, int PU, int D, bool NT, typename RsrcOf>
+template <int T, int PU, int LU, int D, bool NT, typename RsrcOf>
 __device__ __forceinline__ void panel_flush(double *mat, int pitch, int b, int NB, const double *pend0, int npend, const double *colv,
                                             const double *nqv, int rpw, const int *pl, const int *pc, const int *tlist, int nt, double *panel,
                                             RsrcOf rsrc_of) {
-    static_assert(PU % 64 == 0 && (PU >= T ? PU % T == 0 : T % PU == 0), "a wave stays within one row segment");
-    constexpr int RS = PU < T ? T / PU : 1; // rows side by side
-    constexpr int U = PU > T ? PU / T : 1;  // units per lane and row
-    constexpr int LU = PU < T ? PU : T;     // lanes across a row segment
+    // LU lanes across a row segment of PU units: U = PU / LU units per lane and row, RS = T / LU rows side by side.  One WAVE per
+    // row (LU = 64, eight units per lane) is what keeps the sweep off the vector ALU: what a pending pivot costs a row apart
+    // from its elements -- coefficient, skip test (:31), pivot-row and pivot-column tests, branches: ~25 instructions -- is
+    // then spread over 16 elements at 2 instructions each; with all 512 lanes across one row (one unit per lane) it was spread
+    // over two, the select-free path was if-converted away, and the sweep ran VALU-bound at 2.7 TB/s.
+    static_assert(LU % 64 == 0 && PU % LU == 0 && T % LU == 0 && PU % 64 == 0, "a wave stays within one row segment");
+    constexpr int RS = T / LU; // rows side by side
+    constexpr int U = PU / LU; // units per lane and row
     constexpr int AUX = NT ? AUX_NT : AUX_PLAIN;
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid)); // (opaque: the lane's LDS and row offsets are recomputed here, not hoisted out of the caller's pivot loop and kept -- or spilled -- there)
@@ -56,66 +60,88 @@ __device__ __forceinline__ void panel_flush(double *mat, int pitch, int b, int N
             }
             if (__builtin_amdgcn_ballot_w64(fl) == 0) fastmask |= 1u << p;
         }
-        for (int k0 = 0; k0 < nt; k0 += RS * D) {
-            double2 x[D][U];
-            int ri[D];
+        // Two sets of D rows in flight per lane, A and B: the loads of both are issued before A is worked on, and by the time a
+        // set's registers are loaded again its stores -- issued a whole set earlier -- have left.  (One set: the next batch's loads
+        // reuse the registers the previous batch's stores read, hipcc waits for those stores to COMPLETE first, and a wave had
+        // one batch of D x 16 bytes per lane per HBM write + read latency in flight: 2.7 TB/s at 16385^2.)
+        const int r_any = tlist[0]; // (a valid slot for the unconditional reads of the rows that are not there)
+        auto load_set = [&](int k0, double2 (&x)[D][U], int (&ri)[D]) __attribute__((always_inline)) {
 #pragma unroll
             for (int d = 0; d < D; d++) {
                 const int k = k0 + d * RS + sub;
-                ri[d] = k < nt ? tlist[k] : -1;
-                const __amdgpu_buffer_rsrc_t rs = rsrc_of(mat + (size_t)(b + NB * (ri[d] < 0 ? tlist[0] : ri[d])) * pitch);
+                ri[d] = k < nt ? tlist[k] : -1; // my row slot of each row in flight (-1: none)
+                const __amdgpu_buffer_rsrc_t rs = rsrc_of(mat + (size_t)(b + NB * (ri[d] < 0 ? r_any : ri[d])) * pitch);
 #pragma unroll
                 for (int u = 0; u < U; u++) x[d][u] = row_ld16<AUX>(rs, 16 * (u0 + lane + u * LU), 0);
             }
+        };
+        auto apply_set = [&](double2 (&x)[D][U], const int (&ri)[D]) __attribute__((always_inline)) {
+            // Everything a pending pivot needs from LDS -- its panel units, its column and pivot-row slot, my rows' coefficients --
+            // is read unconditionally at the top of its turn: ONE LDS latency per pending pivot and set (a read followed by the
+            // branch that depends on it, row after row, is a chain of LDS round trips).
 #pragma unroll 1
             for (int p = 0; p < npend; p++) {
-                double2 pn[U];
+                constexpr int UH = U > 4 ? 4 : U; // units of the pending row in registers at a time
+                double cf_c[D];
 #pragma unroll
-                for (int u = 0; u < U; u++) pn[u] = *reinterpret_cast<const double2 *>(panel + (size_t)p * 2 * PU + 2 * (lane + u * LU));
+                for (int d = 0; d < D; d++) cf_c[d] = colv[p * rpw + (ri[d] < 0 ? r_any : ri[d])];
                 const int colxp = pc[p], lslotp = pl[p];
                 const bool fastp = (fastmask >> p) & 1u;
                 const int pcu = (colxp >> 1) - u0; // the pivot column's unit within this panel (uniform; in range or not)
                 const bool col_here = (unsigned)pcu < (unsigned)PU;
 #pragma unroll
-                for (int d = 0; d < D; d++) {
-                    if (ri[d] < 0) continue; // (uniform per wave)
-                    const double coef = colv[p * rpw + ri[d]];
-                    const bool piv = ri[d] == lslotp;
-                    if (!(piv || fabs(coef) > 1e-16)) continue; // :31
+                for (int ub = 0; ub < U; ub += UH) {
+                    double2 pn_c[UH];
 #pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        double2 &xv = x[d][u];
-                        if (fastp && !piv) {
-                            const double px = coef * pn[u].x, py = coef * pn[u].y;
-                            xv.x = xv.x - px;
-                            xv.y = xv.y - py;
+                    for (int u = 0; u < UH; u++) pn_c[u] = *reinterpret_cast<const double2 *>(panel + (size_t)p * 2 * PU + 2 * (lane + (ub + u) * LU));
+                    __builtin_amdgcn_sched_barrier(0); // (the reads above stay together, in front of the arithmetic)
+#pragma unroll
+                    for (int d = 0; d < D; d++) {
+                        const double coef = cf_c[d];
+                        const bool piv = ri[d] == lslotp;
+                        if (ri[d] < 0 || !(piv || fabs(coef) > 1e-16)) continue; // (uniform per wave) :31
+                        if (fastp && !piv) { // (uniform) nothing of this panel's slice of the pivot row was flushed: two instructions per element
+#pragma unroll
+                            for (int u = 0; u < UH; u++) {
+                                double2 &xv = x[d][ub + u];
+                                const double px = coef * pn_c[u].x, py = coef * pn_c[u].y;
+                                xv.x = xv.x - px;
+                                xv.y = xv.y - py;
+                            }
                         } else {
-                            const bool f0 = (unsigned long long)__double_as_longlong(pn[u].x) != FLUSHED;
-                            const bool f1 = (unsigned long long)__double_as_longlong(pn[u].y) != FLUSHED;
-                            if (piv) {
-                                xv.x = f0 ? pn[u].x : 0.0;
-                                xv.y = f1 ? pn[u].y : 0.0;
-                            } else {
-                                const double px = coef * pn[u].x, py = coef * pn[u].y;
-                                const double nx = xv.x - px, ny = xv.y - py;
-                                xv.x = f0 ? nx : xv.x;
-                                xv.y = f1 ? ny : xv.y;
+#pragma unroll
+                            for (int u = 0; u < UH; u++) {
+                                double2 &xv = x[d][ub + u];
+                                const double2 pn = pn_c[u];
+                                const bool f0 = (unsigned long long)__double_as_longlong(pn.x) != FLUSHED;
+                                const bool f1 = (unsigned long long)__double_as_longlong(pn.y) != FLUSHED;
+                                if (piv) {
+                                    xv.x = f0 ? pn.x : 0.0;
+                                    xv.y = f1 ? pn.y : 0.0;
+                                } else {
+                                    const double px = coef * pn.x, py = coef * pn.y;
+                                    const double nx = xv.x - px, ny = xv.y - py;
+                                    xv.x = f0 ? nx : xv.x;
+                                    xv.y = f1 ? ny : xv.y;
+                                }
                             }
                         }
-                    }
-                    if (col_here) { // (uniform) :25, :36 -- the one element of the row that the pivot column replaces
-                        const double patch = nqv[p * rpw + ri[d]];
+                        if (col_here) { // (uniform; one panel in npanel) :25, :36 -- the one element of the row that the pivot column replaces
+                            const double patch = nqv[p * rpw + ri[d]];
 #pragma unroll
-                        for (int u = 0; u < U; u++)
-                            if (pcu == lane + u * LU) {
-                                if (colxp & 1)
-                                    x[d][u].y = patch;
-                                else
-                                    x[d][u].x = patch;
-                            }
+                            for (int u = 0; u < UH; u++)
+                                if (pcu == lane + (ub + u) * LU) {
+                                    if (colxp & 1)
+                                        x[d][ub + u].y = patch;
+                                    else
+                                        x[d][ub + u].x = patch;
+                                }
+                        }
                     }
                 }
             }
+        };
+        auto store_set = [&](const double2 (&x)[D][U], const int (&ri)[D]) __attribute__((always_inline)) {
 #pragma unroll
             for (int d = 0; d < D; d++) {
                 if (ri[d] < 0) continue;
@@ -123,7 +149,120 @@ __device__ __forceinline__ void panel_flush(double *mat, int pitch, int b, int N
 #pragma unroll
                 for (int u = 0; u < U; u++) row_st16<AUX>(rs, 16 * (u0 + lane + u * LU), 0, x[d][u]);
             }
+        };
+#pragma unroll 1
+        for (int k0 = 0; k0 < nt; k0 += 2 * RS * D) {
+            double2 xa[D][U], xb[D][U];
+            int ria[D], rib[D];
+            load_set(k0, xa, ria);
+            load_set(k0 + RS * D, xb, rib);
+            apply_set(xa, ria);
+            store_set(xa, ria);
+            apply_set(xb, rib);
+            store_set(xb, rib);
         }
     }
     __syncthreads(); // (the panel LDS may be reused by the caller)
+}
+
+// ------------------------------------------------------------------------------------------
+// direct_flush: the same sweep WITHOUT the LDS panels -- round 2's form: RB (half-)rows of JH units per lane in registers, the
+// pending rows' units read from L2 once per RB rows.  For workgroups with few rows (a rank's share of a row-sharded
+// tableau: 8 rows per workgroup at 2049 x 16385) the panels cost more than they save: per panel two barriers and an LDS fill
+// of npend x 8 KB against 8 rows x 8 KB of row data (measured: 46 -> 53 us per pivot with panels there, 144 -> 107 at
+// 64 rows per workgroup).  The host picks by rows per workgroup (yalps_hip.hip, DSHARD_PANEL_MIN_ROWS).
+// Lane `tid` holds units tid, tid + T, ... of a row; lane_off = 16 * tid.
+// ------------------------------------------------------------------------------------------
+template <int T, int J, bool NT, typename RsrcOf>
+__device__ __forceinline__ void direct_flush(double *mat, int pitch, int b, int NB, const double *pend0, int npend, const double *colv,
+                                             const double *nqv, int rpw, const int *pl, const int *pc, const int *tlist, int nt, RsrcOf rsrc_of) {
+    constexpr int JH = J > 8 ? 8 : J, RB = J > 8 ? 4 : 3, JA = JH;
+    constexpr int AUX = NT ? AUX_NT : AUX_PLAIN;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane_off = 16 * tid;
+#pragma unroll 1
+    for (int u0 = 0; u0 < J; u0 += JH) {
+#pragma unroll 1
+        for (int k = 0; k < nt; k += RB) {
+            double2 xb[RB][JH];
+            int ri[RB];
+#pragma unroll
+            for (int u = 0; u < RB; u++) {
+                ri[u] = tlist[k + u < nt ? k + u : k];
+                const __amdgpu_buffer_rsrc_t rs = rsrc_of(mat + (size_t)(b + NB * ri[u]) * pitch);
+                if (k + u < nt) {
+#pragma unroll
+                    for (int j = 0; j < JH; j++) xb[u][j] = row_ld16<AUX>(rs, lane_off + 16 * T * (u0 + j), 0);
+                }
+            }
+            const int cnt = nt - k;
+#pragma unroll 1
+            for (int p = 0; p < npend; p++) {
+                const __amdgpu_buffer_rsrc_t rsp = rsrc_of(pend0 + (size_t)p * pitch);
+                const int colxp = pc[p], lslotp = pl[p];
+                // the one element of a row that the pivot column replaces (:25, :36): unit `up` of lane `lp`
+                const int up = (colxp >> 1) / T;
+                const bool lane_p = ((colxp >> 1) % T) == tid;
+                double coefu[RB], patchu[RB];
+                bool pivu[RB], actu[RB];
+#pragma unroll
+                for (int u = 0; u < RB; u++) {
+                    coefu[u] = colv[p * rpw + ri[u]];
+                    patchu[u] = nqv[p * rpw + ri[u]];
+                    pivu[u] = ri[u] == lslotp;
+                    actu[u] = u < cnt && (pivu[u] || fabs(coefu[u]) > 1e-16); // :31
+                }
+                double2 pn[JA];
+#pragma unroll
+                for (int j = 0; j < JA; j++) pn[j] = row_ld16<AUX_PLAIN>(rsp, lane_off + 16 * T * (u0 + j), 0);
+                bool fl = false; // (per wave: nothing of these units was flushed -> the select-free path)
+#pragma unroll
+                for (int j = 0; j < JA; j++)
+                    fl = fl || (unsigned long long)__double_as_longlong(pn[j].x) == FLUSHED || (unsigned long long)__double_as_longlong(pn[j].y) == FLUSHED;
+                const bool fastp = __builtin_amdgcn_ballot_w64(fl) == 0;
+#pragma unroll
+                for (int u = 0; u < RB; u++) {
+                    if (!actu[u]) continue; // (uniform)
+#pragma unroll
+                    for (int j = 0; j < JA; j++) {
+                        double2 &xv = xb[u][j];
+                        if (fastp && !pivu[u]) {
+                            const double px = coefu[u] * pn[j].x, py = coefu[u] * pn[j].y;
+                            xv.x = xv.x - px;
+                            xv.y = xv.y - py;
+                        } else {
+                            const bool f0 = (unsigned long long)__double_as_longlong(pn[j].x) != FLUSHED;
+                            const bool f1 = (unsigned long long)__double_as_longlong(pn[j].y) != FLUSHED;
+                            if (pivu[u]) {
+                                xv.x = f0 ? pn[j].x : 0.0;
+                                xv.y = f1 ? pn[j].y : 0.0;
+                            } else {
+                                const double px = coefu[u] * pn[j].x, py = coefu[u] * pn[j].y;
+                                const double nx = xv.x - px, ny = xv.y - py;
+                                xv.x = f0 ? nx : xv.x;
+                                xv.y = f1 ? ny : xv.y;
+                            }
+                        }
+                        if (up == u0 + j) { // (uniform)
+                            if (lane_p) {
+                                if (colxp & 1)
+                                    xv.y = patchu[u];
+                                else
+                                    xv.x = patchu[u];
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < RB; u++) {
+                if (k + u < nt) {
+                    const __amdgpu_buffer_rsrc_t rs = rsrc_of(mat + (size_t)(b + NB * ri[u]) * pitch);
+#pragma unroll
+                    for (int j = 0; j < JH; j++) row_st16<AUX>(rs, lane_off + 16 * T * (u0 + j), 0, xb[u][j]);
+                }
+            }
+        }
+    }
 }

@@ -17,13 +17,13 @@ namespace {
 #include "sweep_kernel.cuh" // (the buffer-descriptor row accessors)
 #include "panel_flush.cuh"
 #include "dshard_kernel.cuh"
-// (R = 1: non-temporal row traffic, for shards beyond the Infinity Cache)
-#define DSVARIANT(T, J, NT) {T, J, NT, reinterpret_cast<const void *>(&dshard_kernel<T, J, NT != 0>)}
+// (R = NT | PANEL << 1: non-temporal row traffic for shards beyond the Infinity Cache; the sweep through LDS panels for shards with many
+// rows per workgroup, straight from L2 for those with few)
+#define DSVARIANT(T, J, NT, PANEL) {T, J, (NT) | ((PANEL) << 1), reinterpret_cast<const void *>(&dshard_kernel<T, J, NT != 0, PANEL != 0>)}
+#define DSVARIANTS(T, J) DSVARIANT(T, J, 0, 0), DSVARIANT(T, J, 1, 0), DSVARIANT(T, J, 0, 1), DSVARIANT(T, J, 1, 1)
 } // namespace
 PersistentTable yalps_dshard_table() {
-    static const PersistentEntry kDshard[] = {DSVARIANT(512, 16, 0), DSVARIANT(512, 16, 1), DSVARIANT(512, 8, 0), DSVARIANT(512, 8, 1),
-                                              DSVARIANT(512, 6, 0),  DSVARIANT(512, 6, 1),  DSVARIANT(512, 4, 0), DSVARIANT(512, 4, 1),
-                                              DSVARIANT(512, 2, 0),  DSVARIANT(512, 2, 1),  DSVARIANT(512, 1, 0), DSVARIANT(512, 1, 1)};
+    static const PersistentEntry kDshard[] = {DSVARIANTS(512, 16), DSVARIANTS(512, 8), DSVARIANTS(512, 6), DSVARIANTS(512, 4), DSVARIANTS(512, 2), DSVARIANTS(512, 1)};
     return {kDshard, (int)(sizeof kDshard / sizeof kDshard[0])};
 }
 const void *yalps_dshard_select_fn() { return reinterpret_cast<const void *>(&dshard_select_kernel); }

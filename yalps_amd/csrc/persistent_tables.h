@@ -40,3 +40,6 @@ PersistentTable yalps_stream3_check_table(); // ... with hasCycle (options.check
 // const double *gather), launch-per-pivot like wide_kernel in MODE_SHARD; R = NT.  dshard_select_kernel: (Desc, int parity, double *send)
 PersistentTable yalps_dshard_table();
 const void *yalps_dshard_select_fn();
+// exchange_floor_kernel<T, J>: the bare hand-off of the resident kernels, for bench.py's measured on-chip floor
+// (persistent_floor.hip): __global__ void (double *rows, unsigned long long *flags, int32_t *err, double *sink, int epochs, int variant)
+const void *yalps_exchange_floor_fn(int lanes, int units);

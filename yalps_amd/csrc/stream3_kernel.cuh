@@ -37,7 +37,6 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
     __shared__ int sh_pl[MAXD], sh_pc[MAXD]; // the pending pivots, oldest first: my slot of the pivot row (-1: not mine), pivot column (mat index)
     __shared__ int sh_fast[MAXD][T / 64];       // per wave: nothing of its slice of that pivot row was flushed (:31 select-free path)
     constexpr int JC = J > 8 ? 8 : J; // units per lane that pass through registers at a time (a pivot row being decided)
-    constexpr int JA = J > 8 ? 8 : J; // ... of a pending pivot row while it is applied to the rows in flight
     extern __shared__ __attribute__((aligned(16))) double sm_dyn[]; // colv[depth][rpw], nqv[depth][rpw], lav[rpw], rhsv[rpw], tlist[rpw] (int), panel[depth][2 PU]
 
     const int tid = threadIdx.x, NB = d.nb, b = blockIdx.x;
@@ -149,46 +148,51 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
     // the pending pivots applied to (up to) RB half-rows held in registers: units [u0, u0 + JH) of my row slots ri[0 .. cnt)
     // (round 3: only the candidate / winner's row that is about to be published goes this way -- one row, JH units of it per lane at
     // a time, the pending rows read from my XCD's scratch; the sweep of all rows is panel_flush.cuh)
-    constexpr int JH = J > 8 ? 8 : J, RB = 1;
+    constexpr int JH = J > 8 ? 4 : J, RB = 1; // (16-unit rows: four units at a time, the units of four pending pivots in flight beside them)
     auto apply_batch = [&](int u0, double2 (&xb)[RB][JH], const int (&ri)[RB], int cnt) __attribute__((always_inline)) {
+        // The pending rows' units come from my XCD's scratch (L2).  The row about to be published is alone on the pivot's chain
+        // here, so what counts is the number of dependent L2 round trips: the units of G pending pivots are loaded at once
+        // (G x JH 16-byte loads per lane in flight) and applied one pivot after the other (round 2: one pivot per trip, JA units:
+        // 2 x npend trips at 16 units per lane -- 11.7 us with 8 pending, twice that with 16).
+        constexpr int G = JH >= 8 ? 2 : JH >= 4 ? 4 : 8; // pending pivots per trip: 16 loads per lane in flight
 #pragma unroll 1
-        for (int p = 0; p < npend; p++) { // (a run-time loop: its scalars are read once per batch of RB half-rows)
-            const __amdgpu_buffer_rsrc_t rsp = rsrc_of(prow0 + (size_t)p * pitch);
-            const int colxp = sh_pc[p], lslotp = sh_pl[p];
-            const bool fastp = sh_fast[p][tid >> 6] != 0;
-            double coefu[RB], patchu[RB];
-            bool pivu[RB], actu[RB];
+        for (int p0 = 0; p0 < npend; p0 += G) {
+            double2 pn[G][JH];
 #pragma unroll
-            for (int u = 0; u < RB; u++) {
-                coefu[u] = colv0[p * rpw + ri[u]];
-                patchu[u] = nqv0[p * rpw + ri[u]];
-                pivu[u] = ri[u] == lslotp;
-                actu[u] = u < cnt && (pivu[u] || fabs(coefu[u]) > 1e-16); // :31
+            for (int g = 0; g < G; g++) {
+                const int p = p0 + g < npend ? p0 + g : p0; // (uniform)
+                const __amdgpu_buffer_rsrc_t rsp = rsrc_of(prow0 + (size_t)p * pitch);
+#pragma unroll
+                for (int j = 0; j < JH; j++) pn[g][j] = row_ld16<AUX_PLAIN>(rsp, lane_off + 16 * T * (u0 + j), 0);
             }
 #pragma unroll
-            for (int jb = 0; jb < JH; jb += JA) {
-                double2 pn[JA];
-#pragma unroll
-                for (int j = 0; j < JA; j++) pn[j] = row_ld16<AUX_PLAIN>(rsp, lane_off + 16 * T * (u0 + jb + j), 0);
+            for (int g = 0; g < G; g++) {
+                const int p = p0 + g;
+                if (p >= npend) break; // (uniform)
+                const int colxp = sh_pc[p], lslotp = sh_pl[p];
+                const bool fastp = sh_fast[p][tid >> 6] != 0;
 #pragma unroll
                 for (int u = 0; u < RB; u++) {
-                    if (!actu[u]) continue; // (uniform)
+                    const double coefu = colv0[p * rpw + ri[u]], patchu = nqv0[p * rpw + ri[u]];
+                    const bool pivu = ri[u] == lslotp;
+                    if (!(u < cnt && (pivu || fabs(coefu) > 1e-16))) continue; // (uniform) :31
 #pragma unroll
-                    for (int j = 0; j < JA; j++) {
-                        const int c0 = 2 * (tid + (u0 + jb + j) * T);
-                        double2 &xv = xb[u][jb + j];
-                        if (fastp && !pivu[u]) {
-                            const double px = coefu[u] * pn[j].x, py = coefu[u] * pn[j].y;
+                    for (int j = 0; j < JH; j++) {
+                        const int c0 = 2 * (tid + (u0 + j) * T);
+                        double2 &xv = xb[u][j];
+                        const double2 pv_ = pn[g][j];
+                        if (fastp && !pivu) {
+                            const double px = coefu * pv_.x, py = coefu * pv_.y;
                             xv.x = xv.x - px;
                             xv.y = xv.y - py;
                         } else {
-                            const bool f0 = (unsigned long long)__double_as_longlong(pn[j].x) != FLUSHED;
-                            const bool f1 = (unsigned long long)__double_as_longlong(pn[j].y) != FLUSHED;
-                            if (pivu[u]) {
-                                xv.x = f0 ? pn[j].x : 0.0;
-                                xv.y = f1 ? pn[j].y : 0.0;
+                            const bool f0 = (unsigned long long)__double_as_longlong(pv_.x) != FLUSHED;
+                            const bool f1 = (unsigned long long)__double_as_longlong(pv_.y) != FLUSHED;
+                            if (pivu) {
+                                xv.x = f0 ? pv_.x : 0.0;
+                                xv.y = f1 ? pv_.y : 0.0;
                             } else {
-                                const double px = coefu[u] * pn[j].x, py = coefu[u] * pn[j].y;
+                                const double px = coefu * pv_.x, py = coefu * pv_.y;
                                 const double nx = xv.x - px, ny = xv.y - py;
                                 xv.x = f0 ? nx : xv.x;
                                 xv.y = f1 ? ny : xv.y;
@@ -196,9 +200,9 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
                         }
                         if (c0 == (colxp & ~1)) {
                             if (colxp & 1)
-                                xv.y = patchu[u];
+                                xv.y = patchu;
                             else
-                                xv.x = patchu[u];
+                                xv.x = patchu;
                         }
                     }
                 }
@@ -224,8 +228,8 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
             if (tl == 0) sh_nt = cnt;
         }
         __syncthreads();
-        // (panel_flush.cuh: the pending rows staged in LDS one 1024-column panel at a time, four rows in flight per lane)
-        panel_flush<T, PU, 4, NT>(mat, pitch, b, NB, prow0, npend, colv0, nqv0, rpw, sh_pl, sh_pc, tlist, sh_nt, panel, rsrc_of);
+        // (panel_flush.cuh: the pending rows staged in LDS one 1024-column panel at a time, a wave per row, eight units per lane, two rows in flight per wave)
+        panel_flush<T, PU, 64, 1, NT>(mat, pitch, b, NB, prow0, npend, colv0, nqv0, rpw, sh_pl, sh_pc, tlist, sh_nt, panel, rsrc_of);
         npend = 0;
         pset ^= 1;
         prow0 = pend_xcd + (size_t)pset * depth * pitch;

@@ -146,7 +146,9 @@ const std::vector<RVariant> kStream3 = variants_of({yalps_stream3_table()});
 const std::vector<RVariant> kStream3Check = variants_of({yalps_stream3_check_table()});
 const std::vector<RVariant> kDshard = variants_of({yalps_dshard_table()}); // (launch-per-pivot: (Desc, parity, mode, force, gather); R = non-temporal row traffic)
 constexpr size_t SWEEP_BEYOND_CACHE = 200u << 20; // tableau bytes from which row traffic goes non-temporal (Infinity Cache: 256 MiB)
-constexpr int STREAM3_DEFAULT_DEPTH_WIDE = 8; // pending pivots of stream3_kernel for rows of 4098+ columns with 8+ rows per workgroup (YALPS_HIP_DELAY_DEPTH)
+constexpr int STREAM3_DEFAULT_DEPTH_WIDE = 16; // pending pivots of stream3_kernel for rows of 4098+ columns with 8+ rows per workgroup (YALPS_HIP_DELAY_DEPTH)
+constexpr int DSHARD_PANEL_MIN_ROWS = 24;      // rows per workgroup from which a row shard's sweep goes through LDS panels (panel_flush.cuh)
+constexpr int DSHARD_DEFAULT_DEPTH_PANEL = 16; // ... and its pending pivots then
 constexpr int DSHARD_DEFAULT_DEPTH = 8; // pending pivots of a row shard (YALPS_HIP_DELAY_DEPTH, at most DSHARD_MAXD = 16)
 constexpr int RESIDENT_CHUNK = 4096; // pivots per launch of the resident kernel (bounds its run time)
 
@@ -356,7 +358,7 @@ struct yalps_tableau {
     Variant var{};
     int wT_inplace = 0;
     KernelFn dfn = nullptr;         // row shard with delayed row updates: dshard_kernel<512, dJ, nt> (d.dpend / dcolv / dnqv / dlav / dstate)
-    int dJ = 0, dnt = 0;
+    int dJ = 0, dnt = 0, dpanel = 0;
     size_t dshmem = 0;
     void *dsh_block = nullptr;      // ... its arrays, one allocation
     int32_t *cyc_block = nullptr;   // row shard: shard_cycle_kernel's verdict words (Desc::cyc_verdict)
@@ -954,7 +956,7 @@ int32_t yalps_tableau_info(const yalps_tableau *t, char *buf, int32_t len) {
         std::snprintf(inp, sizeof inp, "%s_kernel<%d,%d%s>", t->sweep ? "sweep" : "stream", t->svar.T, t->svar.J, t->sweep && t->d.sw_nt ? ",nt" : "");
     char str[64];
     if (t->dfn)
-        std::snprintf(str, sizeof str, "dshard_kernel<512,%d%s>,delay_depth:%d", t->dJ, t->dnt ? ",nt" : "", t->d.delay_depth);
+        std::snprintf(str, sizeof str, "dshard_kernel<512,%d%s%s>,delay_depth:%d", t->dJ, t->dnt ? ",nt" : "", t->dpanel ? ",panel" : "", t->d.delay_depth);
     else if (t->wfn)
         std::snprintf(str, sizeof str, "wide_kernel<%d,%d>", t->var.T, t->var.J);
     else
@@ -985,6 +987,52 @@ int32_t yalps_tableau_debug_stamps(yalps_tableau *t, uint64_t *out, int32_t cap_
     (void)t, (void)out, (void)cap_words, (void)reset;
     return fail(YALPS_E_ARG, "yalps_tableau_debug_stamps: this is not the diagnostic build (-DYALPS_STAMPS)");
 #endif
+}
+
+int32_t yalps_ctx_exchange_floor(yalps_ctx *c, int32_t workgroups, int32_t lanes, int32_t units, int32_t epochs, int32_t variant,
+                                 float *us_per_epoch_out) {
+    // measurement hook (bench.py: roofline.onchip_floor): `epochs` rounds of the resident kernels' exchange and nothing else
+    if (!c || !us_per_epoch_out || workgroups < 1 || workgroups > MAX_BLOCKS || epochs < 1)
+        return fail(YALPS_E_ARG, "yalps_ctx_exchange_floor: bad argument");
+    using FloorFn = void (*)(double *, unsigned long long *, int32_t *, double *, int, int);
+    const FloorFn fn = reinterpret_cast<FloorFn>(const_cast<void *>(yalps_exchange_floor_fn(lanes, units)));
+    if (!fn) return fail(YALPS_E_ARG, "yalps_ctx_exchange_floor: no such variant (lanes x units: 512x2, 512x3, 256x1, 256x2)");
+    HIP_TRY(hipSetDevice(c->device));
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(fn), lanes, 0));
+    if (per_cu < 1 || workgroups > c->num_cus * per_cu) return fail(YALPS_E_ARG, "yalps_ctx_exchange_floor: the grid would not be co-resident");
+    const size_t row_bytes = sizeof(double) * 2 * (size_t)units * lanes, rows_bytes = 2 * (size_t)workgroups * row_bytes;
+    const size_t flag_bytes = 2 * (size_t)workgroups * 16, sink_bytes = sizeof(double) * (size_t)workgroups * lanes;
+    char *block = nullptr;
+    HIP_TRY(hipMalloc(&block, rows_bytes + flag_bytes + 16 + sink_bytes));
+    hipStream_t s = c->stream;
+    int32_t herr = 0;
+    float ms = 0.f;
+    hipError_t e = hipMemsetAsync(block, 0, rows_bytes + flag_bytes + 16, s);
+    {
+        std::lock_guard<std::mutex> one_grid(persistent_mutex(c->device));
+        DeviceLock one_grid_of_all_processes(c->lock_fd, c->lock_wait_ms);
+        if (e == hipSuccess && !one_grid_of_all_processes.held) {
+            (void)hipFree(block);
+            return fail(YALPS_E_DEVICE, "yalps_ctx_exchange_floor: the device's lock file is held by another process");
+        }
+        if (e == hipSuccess) e = hipEventRecord(c->ev0, s);
+        if (e == hipSuccess) {
+            fn<<<dim3(workgroups), dim3(lanes), 0, s>>>(reinterpret_cast<double *>(block), reinterpret_cast<unsigned long long *>(block + rows_bytes),
+                                                        reinterpret_cast<int32_t *>(block + rows_bytes + flag_bytes),
+                                                        reinterpret_cast<double *>(block + rows_bytes + flag_bytes + 16), epochs, variant);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipEventRecord(c->ev1, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    if (e == hipSuccess) e = hipMemcpy(&herr, block + rows_bytes + flag_bytes, sizeof herr, hipMemcpyDeviceToHost);
+    (void)hipFree(block);
+    if (e != hipSuccess) return fail(YALPS_E_DEVICE, std::string("yalps_ctx_exchange_floor: ") + hipGetErrorString(e));
+    if (herr) return fail(YALPS_E_DEVICE, "yalps_ctx_exchange_floor: the grid gave up waiting (device shared with other work?)");
+    *us_per_epoch_out = ms * 1000.f / (float)epochs;
+    return 0;
 }
 
 int32_t yalps_tableau_padding_check(yalps_tableau *t, int64_t *nonfinite_out, int64_t *nonzero_out) {
@@ -1884,23 +1932,30 @@ int32_t yalps_tableau_set_shard(yalps_tableau *t, int32_t rank, int32_t nranks, 
             // a launch-per-pivot step has a larger fixed part than stream3_kernel's, the deepest form wins everywhere)
             // round 3: the sweep stages the pending rows in LDS one 1024-column panel at a time (panel_flush.cuh) -- up to 16
             // pending pivots; the deepest form whose scalars + panel fit the LDS of a CU
-            int depth = std::min(DSHARD_MAXD, std::max(2, env_int("YALPS_HIP_DELAY_DEPTH", DSHARD_DEFAULT_DEPTH)));
+            // the sweep through LDS panels pays from DSHARD_PANEL_MIN_ROWS rows per workgroup on (below: the pending rows straight from L2,
+            // at most 8 pending pivots) -- YALPS_HIP_SHARD_PANEL=0|1 forces one or the other
+            const bool panel = env_int("YALPS_HIP_SHARD_PANEL", rows_per_block >= DSHARD_PANEL_MIN_ROWS ? 1 : 0) != 0;
+            // (measured, one rank, 16385 columns, us per pivot: 2049 rows -- 8 per workgroup -- straight from L2 48 at depth 8, panels 52;
+            // 4097 rows 63 / 59.5 at depth 8 / 16 from L2, panels 60; 8193 rows 91 from L2, panels 86 / 74 at depth 8 / 16; 16385 rows panels 102)
+            const int depth_default = panel ? DSHARD_DEFAULT_DEPTH_PANEL : rows_per_block >= 12 ? 16 : DSHARD_DEFAULT_DEPTH;
+            int depth = std::min(DSHARD_MAXD, std::max(2, env_int("YALPS_HIP_DELAY_DEPTH", depth_default)));
             auto lds_of = [&](int dep) {
                 return sizeof(double) * (2 * (size_t)dep + 2) * (size_t)rows_per_block + sizeof(int32_t) * (((size_t)rows_per_block + 3) / 4 * 4) +
-                       sizeof(double) * (size_t)dep * 2 * DSHARD_PANEL_UNITS;
+                       (panel ? sizeof(double) * (size_t)dep * 2 * DSHARD_PANEL_UNITS : 0);
             };
             while (depth > 2 && lds_of(depth) > 150 * 1024) depth--;
             const bool nt = env_int("YALPS_HIP_SHARD_NT", sizeof(double) * (size_t)d.pitch * (size_t)t->height > SWEEP_BEYOND_CACHE ? 1 : 0) != 0;
             const size_t lds = lds_of(depth);
             if (lds <= 150 * 1024)
                 for (const RVariant &v : kDshard)
-                    if (v.T == 512 && v.J == dJ && v.R == (nt ? 1 : 0)) t->dfn = reinterpret_cast<KernelFn>(v.fn);
+                    if (v.T == 512 && v.J == dJ && v.R == ((nt ? 1 : 0) | (panel ? 2 : 0))) t->dfn = reinterpret_cast<KernelFn>(v.fn);
             if (t->dfn) {
                 if (lds > 48 * 1024)
                     if (int rc = allow_big_lds(t->ctx->device, reinterpret_cast<const void *>(t->dfn))) return rc;
                 t->dshmem = lds;
                 t->dJ = dJ;
                 t->dnt = nt ? 1 : 0;
+                t->dpanel = panel ? 1 : 0;
                 d.delay_depth = depth;
                 if (t->dsh_block) HIP_TRY(hipFree(t->dsh_block));
                 t->dsh_block = nullptr;
