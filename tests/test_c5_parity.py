@@ -86,15 +86,19 @@ def _run_workers(kind, world, variant, budget, tmp_path, env_extra=None):
     return np.load(out)
 
 
-@pytest.mark.parametrize("kind,world,variant", [("hip-rccl", 1, "phase2"), ("hip-rccl", 1, "phase1"), ("hip-native", 2, "phase2"),
-                                                ("hip-native", 2, "phase1"), ("hip", 2, "phase1")])
-def test_c5_row_shards_against_the_oracle(tmp_path, kind, world, variant):
+# (two processes sharing one GPU take ~0.24 s per pivot at this size -- the card alternates between their contexts for every
+# kernel --, so only one of the two-rank cases runs the full 333 pivots per phase; the others stop after 61 / 45, still between
+# two sweeps of the depth-16 form and with both scratch parities used)
+@pytest.mark.parametrize("kind,world,variant,budget", [("hip-rccl", 1, "phase2", _c5.BUDGET), ("hip-rccl", 1, "phase1", _c5.BUDGET),
+                                                       ("hip-native", 2, "phase2", _c5.BUDGET), ("hip-native", 2, "phase1", 61),
+                                                       ("hip", 2, "phase1", 45)])
+def test_c5_row_shards_against_the_oracle(tmp_path, kind, world, variant, budget):
     """The row-sharded path with delayed row updates (dshard_kernel<512,16,nt,panel>, depth 16, the library's own loop): one rank
     holding all rows over RCCL (ncclAllGather between the kernels, batches of 64 pivots as hipGraph replays), and two ranks
     sharing the test GPU over the host transport (8192 rows each, the candidate rows travel with the pending pivots applied);
     the last case drives the same kernels from the Python loop over gloo (yalps_amd/sharded.py::sharded_simplex)."""
-    ref = _c5.reference(variant)
-    res = _run_workers(kind, world, variant, _c5.BUDGET, tmp_path)
+    ref = _c5.reference(variant, budget)
+    res = _run_workers(kind, world, variant, budget, tmp_path)
     assert str(res["kernel"]).startswith("dshard_kernel<512,16,nt,panel>"), res["kernel"]
     assert (str(res["status"]), int(res["pivots"])) == (ref["status"], ref["pivots"]) and _same(float(res["result"]), ref["result"])
     assert np.array_equal(res["pos"], ref["pos"]) and np.array_equal(res["var"], ref["var"])

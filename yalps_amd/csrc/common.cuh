@@ -52,6 +52,18 @@ struct alignas(16) DelayState {
     int32_t pl[16]; // per pending pivot, oldest first: the pivot row as a LOCAL row of this rank (-1: another rank's)
     int32_t pc[16]; // ... its pivot column (mat index)
 };
+// rows in flight per wave in the panel sweep (panel_flush.cuh): YALPS_PANEL_SETS register sets of YALPS_PANEL_D rows of 8 units
+// (same-box A/B, 16385 columns: two rows sharing every read of a pending row's units -- D 2, one set -- against one row in each of
+// two sets: stream3 16385^2 9.06 -> 8.60 s per whole solve, dshard 16385 rows 101.8 -> 97.4 us per pivot, 8193 rows 73.8 -> 71.0;
+// two sets of two rows: no better, 203 registers)
+#ifndef YALPS_PANEL_D
+#define YALPS_PANEL_D 2
+#endif
+#ifndef YALPS_PANEL_SETS
+#define YALPS_PANEL_SETS 1
+#endif
+constexpr int HP_SCAL = 8 + 2 * 16; // doubles a workgroup publishes with its candidate's key in stream3_kernel's two-step exchange: [0] the row's
+                                    // RHS entry, [1] bit p: it was pending pivot p's pivot row, [8 + p] its entry of p's column as it was, [8 + 16 + p] what replaces it
 constexpr int STREAM3_MAXD = 16;         // pending pivots stream3_kernel can hold (the depth in use is Desc::delay_depth)
 constexpr int STREAM3_PANEL_UNITS = 512; // 16-byte units of a row per LDS panel of its sweep (panel_flush.cuh): 1024 columns
 constexpr int DSHARD_MAXD = 16;          // pending pivots a row shard can hold (dshard_kernel.cuh); the depth in use is Desc::delay_depth
@@ -88,7 +100,13 @@ struct Desc {
     unsigned long long *rc_flag[2]; // [nb][2] {candidate key bits, (epoch << 32) | global row index}
     int32_t *rc_err;                // set when a workgroup gives up waiting (never expected)
     unsigned long long *rc_verdict; // [2] checkCycles: workgroup 0's verdict on the pivot of an epoch, (epoch << 32) | cycled
-    unsigned long long *rc_rowflag; // [2][2] stream3_kernel's two-step exchange: {RHS entry of the winner's row, (epoch << 32) | row}, by epoch parity
+    unsigned long long *rc_rowflag; // [2][2] (round 2's two-step exchange of stream3_kernel; unused since the winner's row is materialised by its owner's XCD)
+    // stream3_kernel's two-step exchange (round 3): [nb] 1 + XCD of every workgroup; [2][nb] "my slice of the winner's row is out" flags
+    // (the epoch); [2][nb][HP_SCAL] the scalars every workgroup publishes with its candidate's key -- all in the zeroed control block
+    double *ob_park; // stream3_kernel: [nb][pitch] where a workgroup parks its objective replica (registers) while it sweeps its rows
+    int32_t *hp_xcc;
+    unsigned long long *hp_flag;
+    double *hp_scal;
     int32_t perm_len;
     int32_t extra;  // resident_kernel<.., true>: rows per workgroup parked in LDS (0: none)
     int32_t xl_ofs; // ... and where they start in the dynamic LDS block, in int32 units (behind var[] / pos[] at capacity)

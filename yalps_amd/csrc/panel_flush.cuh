@@ -22,7 +22,7 @@
 // were and what replaces them; pl[p] = my slot of pending pivot p's pivot row or -1, pc[p] = its pivot column (mat index);
 // tlist[0 .. nt) = my row slots touched by at least one pending pivot.  Rows and pending rows are addressed through buffer
 // descriptors of one row (rsrc_of): units past the pitch read as 0.0 and their stores are dropped.
-template <int T, int PU, int LU, int D, bool NT, typename RsrcOf>
+template <int T, int PU, int LU, int D, int SETS, bool NT, typename RsrcOf>
 __device__ __forceinline__ void panel_flush(double *mat, int pitch, int b, int NB, const double *pend0, int npend, const double *colv,
                                             const double *nqv, int rpw, const int *pl, const int *pc, const int *tlist, int nt, double *panel,
                                             RsrcOf rsrc_of) {
@@ -150,16 +150,19 @@ __device__ __forceinline__ void panel_flush(double *mat, int pitch, int b, int N
                 for (int u = 0; u < U; u++) row_st16<AUX>(rs, 16 * (u0 + lane + u * LU), 0, x[d][u]);
             }
         };
+        static_assert(SETS == 1 || SETS == 2, "register sets of D rows in flight per wave");
 #pragma unroll 1
-        for (int k0 = 0; k0 < nt; k0 += 2 * RS * D) {
-            double2 xa[D][U], xb[D][U];
-            int ria[D], rib[D];
+        for (int k0 = 0; k0 < nt; k0 += SETS * RS * D) {
+            double2 xa[D][U], xb[SETS == 2 ? D : 1][U];
+            int ria[D], rib[SETS == 2 ? D : 1];
             load_set(k0, xa, ria);
-            load_set(k0 + RS * D, xb, rib);
+            if constexpr (SETS == 2) load_set(k0 + RS * D, xb, rib);
             apply_set(xa, ria);
             store_set(xa, ria);
-            apply_set(xb, rib);
-            store_set(xb, rib);
+            if constexpr (SETS == 2) {
+                apply_set(xb, rib);
+                store_set(xb, rib);
+            }
         }
     }
     __syncthreads(); // (the panel LDS may be reused by the caller)

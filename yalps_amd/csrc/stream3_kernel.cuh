@@ -23,6 +23,10 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
     __shared__ double sh_q, sh_c0; // quotient; objective-row entry of the pivot column
     __shared__ int sh_fail, sh_nt, sh_flag, sh_verdict;
     __shared__ double sh_rowrhs;
+    // two-step exchange, round 3: the winner's row is materialised by ALL workgroups of its owner's XCD in column slices
+    __shared__ unsigned char sh_xcc[256]; // everybody's XCD (1 + HW_REG_XCC_ID), read once per launch from d.hp_xcc
+    __shared__ double sh_hs[HP_SCAL];     // the winner's row's scalars as its owner published them (layout: publish())
+    __shared__ int sh_hk[2];              // my index among the workgroups of my XCD, and their number
     constexpr int MAXD = STREAM3_MAXD;
     constexpr int PU = STREAM3_PANEL_UNITS; // 16-byte units of a row per LDS panel of the sweep (panel_flush.cuh)
     // TWO: the exchange in two steps -- every workgroup publishes its candidate's KEY only; the workgroup that owns the winner
@@ -104,6 +108,12 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
     for (int j = 0; j < J; j++) ob[j] = row_ld16<AUX_PLAIN>(rsrc_of(mat), lane_off + 16 * T * j, 0);
     for (int i = tid; i < my_rows; i += T) rhsv[i] = rhs[b + NB * i];
     if (tid == 0) sh_fail = 0;
+    if constexpr (TWO) { // my XCD, for everybody: out before my first key record
+        if (tid == 0) {
+            __hip_atomic_store(d.hp_xcc + b, (xcc & 7) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
     __syncthreads();
 
     // ---- the pending pivots (npend of them, [0] the oldest): scalars, pivot rows and my rows' pivot-column entries in LDS ----
@@ -229,7 +239,20 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
         }
         __syncthreads();
         // (panel_flush.cuh: the pending rows staged in LDS one 1024-column panel at a time, a wave per row, eight units per lane, two rows in flight per wave)
-        panel_flush<T, PU, 64, 1, NT>(mat, pitch, b, NB, prow0, npend, colv0, nqv0, rpw, sh_pl, sh_pc, tlist, sh_nt, panel, rsrc_of);
+        // Wide rows: the objective replica's 4 J registers per lane are parked in global memory for the duration of the sweep (2 x
+        // 8 w bytes per workgroup and sweep against 16 w bytes per ROW): with them live, the 16-unit forms spill in the sweep.
+        constexpr bool PARK = J > 8;
+        if constexpr (PARK) {
+            const __amdgpu_buffer_rsrc_t rpk = rsrc_of(d.ob_park + (size_t)b * pitch);
+#pragma unroll
+            for (int j = 0; j < J; j++) row_st16<AUX_PLAIN>(rpk, lane_off + 16 * T * j, 0, ob[j]);
+        }
+        panel_flush<T, PU, 64, YALPS_PANEL_D, YALPS_PANEL_SETS, NT>(mat, pitch, b, NB, prow0, npend, colv0, nqv0, rpw, sh_pl, sh_pc, tlist, sh_nt, panel, rsrc_of);
+        if constexpr (PARK) { // (same lane, same addresses: the stores above are ordered in front of these loads)
+            const __amdgpu_buffer_rsrc_t rpk = rsrc_of(d.ob_park + (size_t)b * pitch);
+#pragma unroll
+            for (int j = 0; j < J; j++) ob[j] = row_ld16<AUX_PLAIN>(rpk, lane_off + 16 * T * j, 0);
+        }
         npend = 0;
         pset ^= 1;
         prow0 = pend_xcd + (size_t)pset * depth * pitch;
@@ -289,6 +312,7 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
         return c;
     };
     unsigned epoch = 0;
+    [[maybe_unused]] bool xcc_ready = false;
     // a row of mine AS IT IS NOW (memory + pending pivots, in registers; not stored in place) -> my slot of the hand-off rows: write-through, drained
     auto publish_row = [&](int par, int cg) __attribute__((always_inline)) {
         if (my_rows > 0) {
@@ -316,6 +340,27 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
         if constexpr (!TWO) {
             if (tid == 0) st_sc1(d.rc_key[par] + b, rhsv[cg]); // the candidate row's RHS entry
             publish_row(par, cg);
+        } else {
+            // TWO: with the key travel the candidate row's SCALARS -- its RHS entry, and per pending pivot its pivot-column entry as it
+            // was, what replaces it, whether it was that pivot's pivot row -- so that, should this row win, the workgroups of my XCD
+            // can run it through the pending pivots in column slices (HP_SCAL doubles, write-through, drained before the record)
+            if (tid < HP_SCAL) {
+                double v = 0.0;
+                if (tid == 0)
+                    v = rhsv[cg];
+                else if (tid == 1) {
+                    int m = 0;
+                    for (int p = 0; p < npend; p++) m |= (sh_pl[p] == cg ? 1 : 0) << p;
+                    v = (double)m;
+                } else if (tid >= 8 && tid < 8 + MAXD) {
+                    if (tid - 8 < npend) v = colv0[(tid - 8) * rpw + cg];
+                } else if (tid >= 8 + MAXD && tid < 8 + 2 * MAXD) {
+                    if (tid - 8 - MAXD < npend) v = nqv0[(tid - 8 - MAXD) * rpw + cg];
+                }
+                st_sc1(d.hp_scal + ((size_t)par * NB + b) * HP_SCAL + tid, v);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
         }
         if (tid == 0) // ONE 16-byte record {candidate key, epoch << 32 | row}, one store, polled with one 16-byte load
             st16_sc1(reinterpret_cast<double *>(d.rc_flag[par] + 2 * b),
@@ -404,23 +449,87 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
         // ---------------- the winner's row as published: the tableau's row after every earlier pivot ----------------
         const double *src = d.rc_rows[par] + (size_t)owner * pitch;
         double rhs_row;
-        if constexpr (TWO) { // the winner's owner publishes the row now; everybody waits for its record {RHS entry, epoch << 32 | row}
-            if (owner == b) {
-                publish_row(par, row / NB);
+        if constexpr (TWO) {
+            // The winner's row, as it is now, into rc_rows[par][owner]: every workgroup of its OWNER'S XCD takes a slice of its
+            // columns -- they share the L2 that holds the owner's rows and that XCD's copy of the pending rows --, loads the row's
+            // units and the pending rows' units (all loads in flight at once), applies the pending pivots with the scalars the owner
+            // published with its key, stores the slice write-through and raises its own flag; everybody waits for those flags.
+            // (Round 2: the owner alone, (1 + npend) x 131 KB through one CU at ~50 GB/s: 11.7 us at 16385 columns with 8
+            // pending, 23 us with 16 -- the largest item of a pivot's head.)
+            if (!xcc_ready) { // once per launch: everybody's XCD (published before the first key record, which I have seen by now)
+                if (tid < NB) sh_xcc[tid] = (unsigned char)__hip_atomic_load(d.hp_xcc + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
                 if (tid == 0) {
-                    sh_rowrhs = rhsv[row / NB];
-                    st16_sc1(reinterpret_cast<double *>(d.rc_rowflag + 2 * par),
-                             make_double2(rhsv[row / NB], __longlong_as_double((long long)(((unsigned long long)epoch << 32) | (unsigned)row))));
+                    int k = 0, K = 0;
+                    for (int w_ = 0; w_ < NB; w_++) {
+                        if (sh_xcc[w_] == sh_xcc[b]) {
+                            if (w_ < b) k++;
+                            K++;
+                        }
+                    }
+                    sh_hk[0] = k;
+                    sh_hk[1] = K;
                 }
-            } else if (tid == 0) {
+                __syncthreads();
+                xcc_ready = true;
+            }
+            const int oxcc = sh_xcc[owner];
+            const double *sc = d.hp_scal + ((size_t)par * NB + owner) * HP_SCAL;
+            if (oxcc == sh_xcc[b]) { // (uniform) I am one of the helpers
+                if (tid < HP_SCAL) sh_hs[tid] = ld_sc1(sc + tid);
+                __syncthreads();
+                const int hk = sh_hk[0], hK = sh_hk[1], units = pitch >> 1;
+                const int per = (units + hK - 1) / hK, u_lo = hk * per, u_hi = u_lo + per < units ? u_lo + per : units;
+                const int pivmask = (int)sh_hs[1];
+                const double *rowp = mat + (size_t)row * pitch;
+                double *dstp = d.rc_rows[par] + (size_t)owner * pitch;
+                for (int u = u_lo + tid; u < u_hi; u += T) {
+                    double2 xv = ld16_sc1_one(rowp + 2 * u); // (sc1: past my L1 -- the row is another workgroup's, written in its sweep)
+#pragma unroll 1
+                    for (int p0 = 0; p0 < npend; p0 += 8) {
+                        double2 pn[8];
+#pragma unroll
+                        for (int g = 0; g < 8; g++)
+                            pn[g] = p0 + g < npend ? ld16_sc1_one(prow0 + (size_t)(p0 + g) * pitch + 2 * u) : make_double2(0.0, 0.0);
+#pragma unroll
+                        for (int g = 0; g < 8; g++) {
+                            const int p = p0 + g;
+                            if (p >= npend) break; // (uniform)
+                            const double coef = sh_hs[8 + p];
+                            const bool piv = (pivmask >> p) & 1;
+                            if (!(piv || fabs(coef) > 1e-16)) continue; // :31
+                            const bool f0 = (unsigned long long)__double_as_longlong(pn[g].x) != FLUSHED;
+                            const bool f1 = (unsigned long long)__double_as_longlong(pn[g].y) != FLUSHED;
+                            if (piv) {
+                                xv.x = f0 ? pn[g].x : 0.0;
+                                xv.y = f1 ? pn[g].y : 0.0;
+                            } else {
+                                const double px = coef * pn[g].x, py = coef * pn[g].y;
+                                const double nx = xv.x - px, ny = xv.y - py;
+                                xv.x = f0 ? nx : xv.x;
+                                xv.y = f1 ? ny : xv.y;
+                            }
+                            const int colxp = sh_pc[p];
+                            if (2 * u == (colxp & ~1)) { // :25, :36
+                                if (colxp & 1)
+                                    xv.y = sh_hs[8 + MAXD + p];
+                                else
+                                    xv.x = sh_hs[8 + MAXD + p];
+                            }
+                        }
+                    }
+                    st16_sc1(dstp + 2 * u, xv);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains ...
+                __syncthreads();                                  // ... before ONE lane raises my flag
+                if (tid == 0)
+                    __hip_atomic_store(d.hp_flag + (size_t)par * NB + b, (unsigned long long)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (tid < NB && sh_xcc[tid] == oxcc) { // everybody: the flags of the owner's XCD
                 unsigned spins = 0;
                 unsigned long long spin_t0 = 0;
                 for (;;) {
-                    const double2 rec = ld16_sc1_one(d.rc_rowflag + 2 * par);
-                    if ((unsigned)((unsigned long long)__double_as_longlong(rec.y) >> 32) == epoch) {
-                        sh_rowrhs = rec.x;
-                        break;
-                    }
+                    if (__hip_atomic_load(d.hp_flag + (size_t)par * NB + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)epoch) break;
                     if (spin_expired(spins, spin_t0, d.rc_err)) {
                         sh_fail = 1;
                         __hip_atomic_store(d.rc_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -429,6 +538,7 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
                     __builtin_amdgcn_s_sleep(2);
                 }
             }
+            if (tid == 0) sh_rowrhs = ld_sc1(sc); // the winner's row's RHS entry
             __syncthreads();
             if (sh_fail) return;
             rhs_row = sh_rowrhs;
@@ -614,20 +724,6 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
         la = __builtin_amdgcn_readfirstlane(best.i == INT_MAX ? 0 : best.i); // (uniform: kept in a scalar register)
         check();
         YSTAMP(6); // arg-max of the pricing (barriers)
-        if (!stop) {
-            if (phase == 2) column_now(la - 1, lav); // my rows' entries of column la after every pivot so far
-            YSTAMP(7); // my rows' entries of the next entering column (scalar chains)
-            publish(candidate(phase));               // (la > 0 here: check() stops phase 2 without an entering column)
-            YSTAMP(8); // my candidate (arg-min), its key record (single hand-off: + the row through the pending pivots)
-        }
-        if (b == 0 && tid == 0) { // basis bookkeeping, :7-12 (off the critical path)
-            const int leaving = d.var[w + row], entering = d.var[col];
-            __hip_atomic_store(d.var + w + row, entering, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(d.var + col, leaving, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            d.pos[leaving] = col;
-            d.pos[entering] = w + row;
-        }
-        // ---------------- the rows: only every depth-th pivot (or on the way out) ----------------------------------------
         // The doubles behind column n of a device row are padding (rows are 128 bytes apart): the pass over the pivot row has marked them
         // FLUSHED like any other zero; the select-free path of the sweep multiplies every lane's units by this row, so the
         // lane that holds them overwrites its own marks with a finite 0.0 (same lane, same address: in order).  The checkCycles
@@ -641,6 +737,26 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
                 (prow0 + (size_t)(npend - 1) * pitch)[c0p + 1] = 0.0;
             }
         }
+        if (!stop) {
+            if (phase == 2) column_now(la - 1, lav); // my rows' entries of column la after every pivot so far
+            YSTAMP(7); // my rows' entries of the next entering column (scalar chains)
+            const KI cand = candidate(phase);        // (la > 0 here: check() stops phase 2 without an entering column)
+            if constexpr (TWO) {
+                // the workgroups of my XCD read my candidate row from memory if it wins: when this pivot's sweep is due it comes
+                // BEFORE my key record (with the key out first, they could read a row I am still sweeping)
+                if (npend == depth) flush_pending();
+            }
+            publish(cand);
+            YSTAMP(8); // my candidate (arg-min), its key record (single hand-off: + the row through the pending pivots)
+        }
+        if (b == 0 && tid == 0) { // basis bookkeeping, :7-12 (off the critical path)
+            const int leaving = d.var[w + row], entering = d.var[col];
+            __hip_atomic_store(d.var + w + row, entering, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(d.var + col, leaving, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            d.pos[leaving] = col;
+            d.pos[entering] = w + row;
+        }
+        // ---------------- the rows: only every depth-th pivot (or on the way out) ----------------------------------------
         YSTAMP(9); // basis bookkeeping (workgroup 0)
         if (npend == depth || stop)
             flush_pending();

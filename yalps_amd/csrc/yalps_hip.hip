@@ -808,7 +808,7 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
         for (int cand : {1, 2, 4, 6, 8, 16})
             if (!sJ && 512 * cand >= units) sJ = cand;
         const int want_kernel = env_int("YALPS_HIP_DELAY_KERNEL", 3);
-        if (want_kernel == 3 && sJ && rows_per_block >= env_int("YALPS_HIP_DELAY_MIN_ROWS", 4)) {
+        if (want_kernel == 3 && sJ && t->nb <= 256 && rows_per_block >= env_int("YALPS_HIP_DELAY_MIN_ROWS", 4)) { // (256: its table of the workgroups' XCDs)
             // depth: a pivot's head grows with the pivots pending (the candidate row gets them all applied before it is
             // published), the sweep shrinks: measured best 8 at 65 and 33 rows per workgroup, 6-8 at 17, 4 at 5-9
             // (with the two-step exchange of the 8- and 16-unit forms only the winner's row gets them applied: 2049 x 16385 at
@@ -834,6 +834,7 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
                 t->sshmem2 = lds3;
                 d.delay_depth = depth3;
                 HIP_TRY(hipMalloc(&d.pend, sizeof(double) * 8 * 2 * (size_t)depth3 * d.pitch)); // (per XCD: two sets of `depth` rows, shared by its workgroups)
+                if (sJ > 8) HIP_TRY(hipMalloc(&d.ob_park, sizeof(double) * (size_t)t->nb * d.pitch)); // (16-unit rows: the objective replicas during a sweep)
                 t->stream3 = true;
             }
         }
@@ -869,7 +870,12 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
         const size_t tag_row = 2 * (size_t)d.pitch + 2;
         const size_t tag_bytes = t->rvar_tag.fn ? sizeof(double) * 2 * (size_t)t->nb * tag_row : 0;
         const size_t sweep_bytes = t->sweep ? ((size_t)yalps_sweep_sync_bytes() + 15) / 16 * 16 + 32 * 2 * (size_t)t->nb : 0;
-        t->rc_sync_bytes = sizeof(unsigned long long) * (2 * nflag + 2) + tag_bytes + sweep_bytes + 32 + 16; // (a multiple of 16; 32: rc_rowflag)
+        // stream3_kernel's two-step exchange: [nb] XCD ids (int32, padded to 16 B) | [2][nb] slice flags | [2][nb][HP_SCAL] candidate scalars
+        const size_t hp_xcc_bytes = t->stream3 ? (sizeof(int32_t) * (size_t)t->nb + 15) / 16 * 16 : 0;
+        const size_t hp_flag_bytes = t->stream3 ? sizeof(unsigned long long) * 2 * (size_t)t->nb : 0;
+        const size_t hp_scal_bytes = t->stream3 ? sizeof(double) * 2 * (size_t)t->nb * HP_SCAL : 0;
+        const size_t hp_bytes = hp_xcc_bytes + hp_flag_bytes + hp_scal_bytes;
+        t->rc_sync_bytes = sizeof(unsigned long long) * (2 * nflag + 2) + tag_bytes + sweep_bytes + hp_bytes + 32 + 16; // (a multiple of 16; 32: rc_rowflag)
         HIP_TRY(hipMalloc(&t->ctl_block, t->rc_sync_bytes + 2 * sizeof(YState) + sizeof(YConst)));
         HIP_TRY(hipMemsetAsync(t->ctl_block, 0, t->rc_sync_bytes + 2 * sizeof(YState) + sizeof(YConst), s));
         t->rc_sync = t->ctl_block;
@@ -885,6 +891,12 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
             char *sw = reinterpret_cast<char *>(base + 2 * nflag + 2) + tag_bytes;
             d.sw_sync = reinterpret_cast<unsigned long long *>(sw);
             d.sw_recs = reinterpret_cast<unsigned long long *>(sw + ((size_t)yalps_sweep_sync_bytes() + 15) / 16 * 16);
+        }
+        if (t->stream3) {
+            char *hp = reinterpret_cast<char *>(base + 2 * nflag + 2) + tag_bytes + sweep_bytes;
+            d.hp_xcc = reinterpret_cast<int32_t *>(hp);
+            d.hp_flag = reinterpret_cast<unsigned long long *>(hp + hp_xcc_bytes);
+            d.hp_scal = reinterpret_cast<double *>(hp + hp_xcc_bytes + hp_flag_bytes);
         }
         char *tail = static_cast<char *>(t->ctl_block) + t->rc_sync_bytes;
         d.rc_err = reinterpret_cast<int32_t *>(tail - 16);
@@ -931,7 +943,7 @@ void yalps_tableau_destroy(yalps_tableau *t) {
     void *bufs[] = {d.mat[0], d.mat[1], d.rhs[0], d.rhs[1], t->perm_block ? nullptr : d.pos, t->perm_block ? nullptr : d.var, t->perm_block,
                     t->ctl_block ? nullptr : d.st, t->ctl_block ? nullptr : d.cst, t->ctl_block, d.rc_rows[0], d.rc_rows[1], t->perm_backup,
                     d.rc_key[0], d.rc_key[1], d.gen_prow, d.gen_scal, d.part_ratio[0], d.part_ratio[1], d.part_rhs[0], d.part_rhs[1],
-                    t->hist[0], t->hist[1], t->cells, d.dbg, d.obj[0], d.pend, t->dsh_block, t->cyc_block};
+                    t->hist[0], t->hist[1], t->cells, d.dbg, d.obj[0], d.pend, d.ob_park, t->dsh_block, t->cyc_block};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (t->host_state) (void)hipHostFree(t->host_state);
