@@ -159,7 +159,8 @@ int32_t yalps_tableau_pivot(yalps_tableau *t, int32_t row, int32_t col);
 
 /* Measurement hook (bench.py `roofline.onchip_floor`): `epochs` rounds of the register-resident kernels' per-pivot exchange
  * and nothing else -- `workgroups` x `lanes`, one per CU, rows of 2 * units * lanes doubles; variant bit 0: every workgroup
- * publishes a row (write-through, drained) before its 16-byte record, bit 1: everybody fetches the winner's row afterwards.
+ * publishes a row (write-through, drained) before its 16-byte record, bit 1: everybody fetches the winner's row afterwards,
+ * bit 2: the two-level exchange (the first workgroup of every XCD gathers its XCD's records and raises one record per XCD).
  * *us_per_epoch_out = HIP-event time / epochs.  (lanes x units: 512x2 = the 16 KB rows of BASELINE config 2, 512x3, 256x1, 256x2.) */
 int32_t yalps_ctx_exchange_floor(yalps_ctx *ctx, int32_t workgroups, int32_t lanes, int32_t units, int32_t epochs, int32_t variant,
                                  float *us_per_epoch_out);

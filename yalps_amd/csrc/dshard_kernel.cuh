@@ -169,7 +169,7 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
         if constexpr (PANEL)
             panel_flush<T, PU, 64, YALPS_PANEL_D, YALPS_PANEL_SETS, NT>(mat, pitch, b, NB, prow0, npend, colv0, nqv0, rpw, sh_pl, sh_pc, tlist, sh_nt, panel, rsrc_of);
         else // (few rows per workgroup: the pending rows straight from L2, round 2's form)
-            direct_flush<T, J, NT>(mat, pitch, b, NB, prow0, npend, colv0, nqv0, rpw, sh_pl, sh_pc, tlist, sh_nt, rsrc_of);
+            direct_flush<T, J, (J > 8 ? 4 : 3), NT>(mat, pitch, b, NB, prow0, npend, colv0, nqv0, rpw, sh_pl, sh_pc, tlist, sh_nt, rsrc_of);
         npend = 0;
     };
     auto write_state = [&](int status, int phase_, int la_, int pbuf_, int swap_valid_, int swap_row_, int swap_col_, int64_t hist_len_,
@@ -484,7 +484,11 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
 // with delayed row updates: the rows leave with the pending pivots applied, element by element, each with its own rounding
 // (the same arithmetic as the sweep: :14-25 for a row that was a pivot row, :31-36 otherwise).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void dshard_select_kernel(Desc d, int parity, double *send) {
+// ST lanes per workgroup: 1024 (up to 1024 partials), or 256 where the shard has at most 256 workgroups -- four times the
+// workgroups for the same units: a lane's chain is (1 + npend) dependent-free loads of ONE unit, and what bounds the kernel is
+// how many CUs pull the pending rows through their L2 ports (2049 x 16385: 46.9 -> 46.4 us per pivot of the whole loop).
+template <int ST>
+__global__ __launch_bounds__(ST) void dshard_select_kernel(Desc d, int parity, double *send) {
     constexpr int MAXD = DSHARD_MAXD;
     __shared__ double sk[2][16];
     __shared__ int si[2][16];
@@ -502,8 +506,8 @@ __global__ __launch_bounds__(1024) void dshard_select_kernel(Desc d, int parity,
         cn.k = c.key;
         cn.i = c.idx;
     }
-    cr = block_argmin<1024>(cr, sk, si, 0);
-    cn = block_argmin<1024>(cn, sk, si, 1);
+    cr = block_argmin<ST>(cr, sk, si, 0);
+    cn = block_argmin<ST>(cn, sk, si, 1);
     const double *mat = d.mat[S->mbuf], *rhs = d.rhs[S->mbuf];
     const int lr = cr.i == INT_MAX ? 0 : cr.i - d.row_base, ln = cn.i == INT_MAX ? 0 : cn.i - d.row_base;
     int npend = idle ? 0 : D->npend;
@@ -531,7 +535,7 @@ __global__ __launch_bounds__(1024) void dshard_select_kernel(Desc d, int parity,
     const int units = pitch / 2;
     const double2 *r0 = reinterpret_cast<const double2 *>(mat + (size_t)lr * pitch), *r1 = reinterpret_cast<const double2 *>(mat + (size_t)ln * pitch);
     double2 *o0 = reinterpret_cast<double2 *>(send + SHARD_HDR), *o1 = reinterpret_cast<double2 *>(send + SHARD_HDR + pitch);
-    for (int u = blockIdx.x * 1024 + tid; u < 2 * units; u += gridDim.x * 1024) {
+    for (int u = blockIdx.x * ST + tid; u < 2 * units; u += gridDim.x * ST) {
         const int which = u < units ? 0 : 1, uu = which ? u - units : u;
         double2 v = which ? r1[uu] : r0[uu];
         double2 pn[MAXD];

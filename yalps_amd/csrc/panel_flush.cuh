@@ -176,10 +176,10 @@ __device__ __forceinline__ void panel_flush(double *mat, int pitch, int b, int N
 // 64 rows per workgroup).  The host picks by rows per workgroup (yalps_hip.hip, DSHARD_PANEL_MIN_ROWS).
 // Lane `tid` holds units tid, tid + T, ... of a row; lane_off = 16 * tid.
 // ------------------------------------------------------------------------------------------
-template <int T, int J, bool NT, typename RsrcOf>
+template <int T, int J, int RB, bool NT, typename RsrcOf>
 __device__ __forceinline__ void direct_flush(double *mat, int pitch, int b, int NB, const double *pend0, int npend, const double *colv,
                                              const double *nqv, int rpw, const int *pl, const int *pc, const int *tlist, int nt, RsrcOf rsrc_of) {
-    constexpr int JH = J > 8 ? 8 : J, RB = J > 8 ? 4 : 3, JA = JH;
+    constexpr int JH = J > 8 ? 8 : J, JA = JH; // (RB (half-)rows of JH units per lane in registers)
     constexpr int AUX = NT ? AUX_NT : AUX_PLAIN;
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));

@@ -26,4 +26,6 @@ PersistentTable yalps_dshard_table() {
     static const PersistentEntry kDshard[] = {DSVARIANTS(512, 16), DSVARIANTS(512, 8), DSVARIANTS(512, 6), DSVARIANTS(512, 4), DSVARIANTS(512, 2), DSVARIANTS(512, 1)};
     return {kDshard, (int)(sizeof kDshard / sizeof kDshard[0])};
 }
-const void *yalps_dshard_select_fn() { return reinterpret_cast<const void *>(&dshard_select_kernel); }
+const void *yalps_dshard_select_fn(int lanes) {
+    return lanes == 256 ? reinterpret_cast<const void *>(&dshard_select_kernel<256>) : reinterpret_cast<const void *>(&dshard_select_kernel<1024>);
+}

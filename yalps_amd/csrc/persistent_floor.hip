@@ -25,14 +25,30 @@ namespace {
 template <int T, int J>
 __global__ __launch_bounds__(T) void exchange_floor_kernel(double *rows, unsigned long long *flags, int32_t *err, double *sink, int epochs,
                                                            int variant) {
-    // rows: [2 parities][NB][2 J T] doubles; flags: [2 parities][NB][2] (zeroed before the launch; epochs count from 1)
+    // rows: [2 parities][NB][2 J T] doubles; flags: [2 parities][NB][2] records, then [2 parities][8][2] XCD records, then [NB] XCD ids
+    // (zeroed before the launch; epochs count from 1)
+    // variant bit 2: the TWO-LEVEL exchange (DESIGN.md 4.2b "XCD-leader"): the first workgroup of every XCD polls the records of
+    // its XCD's workgroups, reduces them and raises ONE record per XCD; everybody polls those (at most 8) instead of NB records.
     __shared__ int sh_fail;
+    __shared__ unsigned char sh_x[1024 + 8]; // everybody's XCD (1 + id); [NB + x]: XCD x has workgroups
+    __shared__ int sh_leader;
     const int tid = threadIdx.x, b = blockIdx.x, NB = gridDim.x, pitch = 2 * J * T;
+    unsigned long long *xrec = flags + (size_t)2 * NB * 2;                              // [2][8][2]
+    int32_t *xtab = reinterpret_cast<int32_t *>(flags + (size_t)2 * NB * 2 + 2 * 8 * 2); // [NB]
     double2 mine[J];
 #pragma unroll
     for (int j = 0; j < J; j++) mine[j] = make_double2((double)(b + j), (double)tid);
     if (tid == 0) sh_fail = 0;
+    int xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+    xcc &= 7;
+    const bool two_level = (variant & 4) != 0;
+    if (two_level && tid == 0) { // my XCD, out before my first record
+        __hip_atomic_store(xtab + b, xcc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
+    bool table_ready = false, leader = false;
     for (int epoch = 1; epoch <= epochs; epoch++) {
         const int par = epoch & 1;
         double *myrow = rows + ((size_t)par * NB + b) * pitch;
@@ -45,7 +61,10 @@ __global__ __launch_bounds__(T) void exchange_floor_kernel(double *rows, unsigne
         if (tid == 0) // (2)
             st16_sc1(reinterpret_cast<double *>(flags + ((size_t)par * NB + b) * 2),
                      make_double2(mine[0].x, __longlong_as_double((long long)(((unsigned long long)(unsigned)epoch << 32) | (unsigned)b))));
-        if (tid < NB) { // (3)
+        // (3) flat: everybody polls everybody.  Two-level (from the second round on: the first one also carries the XCD table):
+        // the XCD's leader polls its XCD's records and raises the XCD's record, everybody polls the XCD records.
+        const bool flat = !two_level || !table_ready;
+        if (tid < NB && (flat || (leader && sh_x[tid] == xcc + 1))) {
             unsigned spins = 0;
             unsigned long long spin_t0 = 0;
             for (;;) {
@@ -59,8 +78,46 @@ __global__ __launch_bounds__(T) void exchange_floor_kernel(double *rows, unsigne
                 __builtin_amdgcn_s_sleep(2);
             }
         }
+        if (!flat) {
+            if (leader) {
+                __syncthreads(); // (the reduction of my XCD's records would sit here)
+                if (tid == 0)
+                    st16_sc1(reinterpret_cast<double *>(xrec + ((size_t)par * 8 + xcc) * 2),
+                             make_double2(mine[0].x, __longlong_as_double((long long)(((unsigned long long)(unsigned)epoch << 32) | (unsigned)b))));
+            }
+            if (tid < 8 && sh_x[NB + tid]) { // (sh_x[NB + x]: XCD x has workgroups)
+                unsigned spins = 0;
+                unsigned long long spin_t0 = 0;
+                for (;;) {
+                    const double2 rec = ld16_sc1_one(xrec + ((size_t)par * 8 + tid) * 2);
+                    if ((unsigned)((unsigned long long)__double_as_longlong(rec.y) >> 32) == (unsigned)epoch) break;
+                    if (spin_expired(spins, spin_t0, err)) {
+                        sh_fail = 1;
+                        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+        }
         __syncthreads();
         if (sh_fail) return;
+        if (two_level && !table_ready) { // everybody's XCD (published before the first record, which I have seen by now)
+            if (tid < NB) sh_x[tid] = (unsigned char)__hip_atomic_load(xtab + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid < 8) sh_x[NB + tid] = 0;
+            __syncthreads();
+            if (tid == 0) {
+                int first = -1;
+                for (int w_ = 0; w_ < NB; w_++) {
+                    if (sh_x[w_] >= 1 && sh_x[w_] <= 8) sh_x[NB + sh_x[w_] - 1] = 1;
+                    if (first < 0 && sh_x[w_] == xcc + 1) first = w_;
+                }
+                sh_leader = first == b ? 1 : 0;
+            }
+            __syncthreads();
+            leader = sh_leader != 0;
+            table_ready = true;
+        }
         if (variant & 2) { // (4) the winner's row: a different workgroup every round, the same for everybody
             const int winner = (int)(((unsigned)epoch * 97u + 13u) % (unsigned)NB);
             const double *src = rows + ((size_t)par * NB + winner) * pitch;

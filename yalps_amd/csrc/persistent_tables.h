@@ -36,10 +36,12 @@ PersistentTable yalps_stream2_table();
 // stream3_kernel<T, J, NT>: the same for rows of 8194 .. 16385 columns: objective replica in LDS, pending pivot rows in a global scratch
 PersistentTable yalps_stream3_table();
 PersistentTable yalps_stream3_check_table(); // ... with hasCycle (options.checkCycles)
+PersistentTable yalps_stream3d_table();      // the same kernels with the pending rows read straight from L2 in the sweep (few rows per workgroup); R = NT | PANEL << 1
+PersistentTable yalps_stream3d_check_table();
 // dshard_kernel<T, J, NT>: one pivot of a row shard with delayed row updates -- __global__ void (Desc, int parity, int, int,
 // const double *gather), launch-per-pivot like wide_kernel in MODE_SHARD; R = NT.  dshard_select_kernel: (Desc, int parity, double *send)
 PersistentTable yalps_dshard_table();
-const void *yalps_dshard_select_fn();
+const void *yalps_dshard_select_fn(int lanes); // lanes per workgroup: 1024, or 256 for shards of at most 256 workgroups
 // exchange_floor_kernel<T, J>: the bare hand-off of the resident kernels, for bench.py's measured on-chip floor
 // (persistent_floor.hip): __global__ void (double *rows, unsigned long long *flags, int32_t *err, double *sink, int epochs, int variant)
 const void *yalps_exchange_floor_fn(int lanes, int units);

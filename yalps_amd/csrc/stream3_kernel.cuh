@@ -16,7 +16,7 @@
 //     two rows during the sweep, single entries for the scalar chains with agent-scope loads;
 //   * a pivot row passes through registers 8 units per lane at a time (normalise, objective replica, pricing in one pass).
 // ------------------------------------------------------------------------------------------
-template <int T, int J, bool NT, bool CHECK = false>
+template <int T, int J, bool NT, bool CHECK = false, bool PANEL = true>
 __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chunk) {
     __shared__ double sk[2][16];
     __shared__ int si[2][16];
@@ -247,7 +247,11 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
 #pragma unroll
             for (int j = 0; j < J; j++) row_st16<AUX_PLAIN>(rpk, lane_off + 16 * T * j, 0, ob[j]);
         }
-        panel_flush<T, PU, 64, YALPS_PANEL_D, YALPS_PANEL_SETS, NT>(mat, pitch, b, NB, prow0, npend, colv0, nqv0, rpw, sh_pl, sh_pc, tlist, sh_nt, panel, rsrc_of);
+        if constexpr (PANEL)
+            panel_flush<T, PU, 64, YALPS_PANEL_D, YALPS_PANEL_SETS, NT>(mat, pitch, b, NB, prow0, npend, colv0, nqv0, rpw, sh_pl, sh_pc, tlist, sh_nt, panel, rsrc_of);
+        else // (few rows per workgroup: the pending rows straight from my XCD's scratch, round 2's form -- the panels' barriers and LDS
+             // fills cost more than they save there: 1025 x 16385, 4 rows per workgroup, 32 -> 38 us per pivot with panels)
+            direct_flush<T, J, (J >= 8 ? 2 : 3), NT>(mat, pitch, b, NB, prow0, npend, colv0, nqv0, rpw, sh_pl, sh_pc, tlist, sh_nt, rsrc_of);
         if constexpr (PARK) { // (same lane, same addresses: the stores above are ordered in front of these loads)
             const __amdgpu_buffer_rsrc_t rpk = rsrc_of(d.ob_park + (size_t)b * pitch);
 #pragma unroll

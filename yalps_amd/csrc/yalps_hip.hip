@@ -142,10 +142,11 @@ const std::vector<RVariant> kStreamCheck = variants_of({yalps_stream_check_table
 const std::vector<RVariant> kSweep = variants_of({yalps_sweep_table()});
 const std::vector<RVariant> kSweepCheck = variants_of({yalps_sweep_check_table()});
 const std::vector<RVariant> kStream2 = variants_of({yalps_stream2_table()}); // (R = non-temporal row traffic)
-const std::vector<RVariant> kStream3 = variants_of({yalps_stream3_table()});
-const std::vector<RVariant> kStream3Check = variants_of({yalps_stream3_check_table()});
+const std::vector<RVariant> kStream3 = variants_of({yalps_stream3_table(), yalps_stream3d_table()});
+const std::vector<RVariant> kStream3Check = variants_of({yalps_stream3_check_table(), yalps_stream3d_check_table()});
 const std::vector<RVariant> kDshard = variants_of({yalps_dshard_table()}); // (launch-per-pivot: (Desc, parity, mode, force, gather); R = non-temporal row traffic)
 constexpr size_t SWEEP_BEYOND_CACHE = 200u << 20; // tableau bytes from which row traffic goes non-temporal (Infinity Cache: 256 MiB)
+constexpr int STREAM3_PANEL_MIN_ROWS = 12; // rows per workgroup from which stream3_kernel's sweep goes through LDS panels (panel_flush.cuh)
 constexpr int STREAM3_DEFAULT_DEPTH_WIDE = 16; // pending pivots of stream3_kernel for rows of 4098+ columns with 8+ rows per workgroup (YALPS_HIP_DELAY_DEPTH)
 constexpr int DSHARD_PANEL_MIN_ROWS = 24;      // rows per workgroup from which a row shard's sweep goes through LDS panels (panel_flush.cuh)
 constexpr int DSHARD_DEFAULT_DEPTH_PANEL = 16; // ... and its pending pivots then
@@ -816,20 +817,28 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
             // 1025 x 16385 31.6 / 31.4 / 32.3)
             // (round 3: the sweep stages the pending rows in LDS one 1024-column panel at a time -- panel_flush.cuh -- and the objective
             // replica moved to registers: up to STREAM3_MAXD = 16 pending pivots, the deepest form whose scalars + panel fit in LDS)
-            const int depth_default = sJ >= 8 ? (rows_per_block >= 8 ? STREAM3_DEFAULT_DEPTH_WIDE : 6) : std::max(4, (rows_per_block + 1) / 3);
-            int depth3 = std::min(STREAM3_MAXD, std::max(2, env_int("YALPS_HIP_DELAY_DEPTH", std::min(depth_default, STREAM3_MAXD))));
+            // The panels pay from STREAM3_PANEL_MIN_ROWS rows per workgroup on (YALPS_HIP_STREAM3_PANEL=0|1 forces); below, the sweep reads
+            // the pending rows straight from the XCD's scratch and the depths are round 2's (shape sweep, us per pivot with panels
+            // / straight from L2, same build: 4 rows per workgroup -- 1025 x 8001 23.6 / 19.1, 1025 x 16385 38.3 / 28.5; 8 rows -- 2049 x 16385
+            // 40.2 / 38.1; 17 rows -- 4097 x 16385 48.9 / 54.9, 4097^2 19.7 / 20.4; 20 rows -- 5001^2 24.8 / 28.2; beyond: panels only,
+            // 6001^2 28.1, 8193^2 37.5, 16385^2 87.8 -- round 2: 33.4, 45.5, 141).
+            const bool panel3 = env_int("YALPS_HIP_STREAM3_PANEL", rows_per_block >= STREAM3_PANEL_MIN_ROWS ? 1 : 0) != 0;
+            const int depth_default = panel3 ? STREAM3_DEFAULT_DEPTH_WIDE
+                                             : std::min(8, sJ >= 8 ? (rows_per_block >= 8 ? 8 : 6) : std::max(4, (rows_per_block + 1) / 3));
+            int depth3 = std::min(STREAM3_MAXD, std::max(2, env_int("YALPS_HIP_DELAY_DEPTH", depth_default)));
             auto lds3_of = [&](int dep) {
                 return sizeof(double) * (2 * (size_t)dep + 2) * (size_t)rows_per_block + sizeof(int32_t) * (((size_t)rows_per_block + 3) / 4 * 4) +
-                       sizeof(double) * (size_t)dep * 2 * STREAM3_PANEL_UNITS;
+                       (panel3 ? sizeof(double) * (size_t)dep * 2 * STREAM3_PANEL_UNITS : 0);
             };
             while (depth3 > 2 && lds3_of(depth3) > 150 * 1024) depth3--;
             const size_t lds3 = lds3_of(depth3);
+            const int want_r = want_nt2 | (panel3 ? 2 : 0);
             if (lds3 <= 150 * 1024)
                 for (const RVariant &v : kStream3)
-                    if (v.T == 512 && v.J == sJ && v.R == want_nt2) t->svar2 = v;
+                    if (v.T == 512 && v.J == sJ && v.R == want_r) t->svar2 = v;
             if (t->svar2.fn)
                 for (const RVariant &v : kStream3Check)
-                    if (v.T == 512 && v.J == sJ && v.R == want_nt2) t->svar2_check = v;
+                    if (v.T == 512 && v.J == sJ && v.R == want_r) t->svar2_check = v;
             if (t->svar2.fn) {
                 t->sshmem2 = lds3;
                 d.delay_depth = depth3;
@@ -963,7 +972,8 @@ int32_t yalps_tableau_info(const yalps_tableau *t, char *buf, int32_t len) {
         std::snprintf(res, sizeof res, "resident%s_kernel<%d,%d,%d%s> chunk=%d lds_rows=%d", t->rgen == 2 && !t->rvar_tag.fn ? "2" : "", t->rvar.T, t->rvar.J, t->rvar.R,
                       t->d.extra ? ",lds" : t->rvar_tag.fn ? ",tag" : "", RESIDENT_CHUNK, t->d.extra);
     if (t->svar2.fn && t->last_delayed)
-        std::snprintf(inp, sizeof inp, "stream%d_kernel<%d,%d%s> delay_depth=%d", t->stream3 ? 3 : 2, t->svar2.T, t->svar2.J, t->svar2.R ? ",nt" : "", t->d.delay_depth);
+        std::snprintf(inp, sizeof inp, "stream%d_kernel<%d,%d%s> delay_depth=%d%s", t->stream3 ? 3 : 2, t->svar2.T, t->svar2.J, (t->svar2.R & 1) ? ",nt" : "", t->d.delay_depth,
+                      t->stream3 ? ((t->svar2.R & 2) ? " sweep=panels" : " sweep=direct") : "");
     else if (t->svar.fn)
         std::snprintf(inp, sizeof inp, "%s_kernel<%d,%d%s>", t->sweep ? "sweep" : "stream", t->svar.T, t->svar.J, t->sweep && t->d.sw_nt ? ",nt" : "");
     char str[64];
@@ -1014,7 +1024,8 @@ int32_t yalps_ctx_exchange_floor(yalps_ctx *c, int32_t workgroups, int32_t lanes
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(fn), lanes, 0));
     if (per_cu < 1 || workgroups > c->num_cus * per_cu) return fail(YALPS_E_ARG, "yalps_ctx_exchange_floor: the grid would not be co-resident");
     const size_t row_bytes = sizeof(double) * 2 * (size_t)units * lanes, rows_bytes = 2 * (size_t)workgroups * row_bytes;
-    const size_t flag_bytes = 2 * (size_t)workgroups * 16, sink_bytes = sizeof(double) * (size_t)workgroups * lanes;
+    const size_t flag_bytes = 2 * (size_t)workgroups * 16 + 2 * 8 * 16 + (sizeof(int32_t) * (size_t)workgroups + 15) / 16 * 16; // records | XCD records | XCD ids
+    const size_t sink_bytes = sizeof(double) * (size_t)workgroups * lanes;
     char *block = nullptr;
     HIP_TRY(hipMalloc(&block, rows_bytes + flag_bytes + 16 + sink_bytes));
     hipStream_t s = c->stream;
@@ -2044,8 +2055,11 @@ static int shard_select_blocks(const yalps_tableau *t) { // 16-byte units of the
 // this rank's candidates + their rows into its slot of the all-gather (delayed row updates: with the pending pivots applied)
 static void launch_select(yalps_tableau *t, double *send) {
     using SelectFn = void (*)(Desc, int, double *);
-    if (t->dfn)
-        reinterpret_cast<SelectFn>(const_cast<void *>(yalps_dshard_select_fn()))<<<dim3(shard_select_blocks(t)), dim3(1024), 0, t->ctx->stream>>>(t->d, t->shard_parity, send);
+    if (t->dfn) {
+        const int lanes = t->nb <= 256 ? 256 : 1024; // (dshard_select_kernel<256>: four times the workgroups)
+        const int blocks = std::min(256, std::max(1, (t->d.pitch + lanes - 1) / lanes));
+        reinterpret_cast<SelectFn>(const_cast<void *>(yalps_dshard_select_fn(lanes)))<<<dim3(blocks), dim3(lanes), 0, t->ctx->stream>>>(t->d, t->shard_parity, send);
+    }
     else
         shard_select_kernel<<<dim3(shard_select_blocks(t)), dim3(1024), 0, t->ctx->stream>>>(t->d, t->shard_parity, send);
 }
