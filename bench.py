@@ -142,6 +142,9 @@ def main():
     ap.add_argument("--shard-rows", type=int, default=0,
                     help="sharded workload: M of dense-LP(M,size,seed) instead of size (one rank's share of a larger world, "
                          "measured on one GPU: e.g. 2048 rows of 16384 columns = a rank of 8)")
+    ap.add_argument("--verify-pivots", type=int, default=48,
+                    help="sharded workload: after the timed run, this many pivots from the fresh input are run again, every rank's rows "
+                         "are hashed and rank 0 compares them with the CPU oracle's (the same run is the workload's cpu_baseline); 0 = skip")
     ap.add_argument("--no-sharded-c5", action="store_true", help="N > 1, default workload: skip the row-sharded config-5 measurement")
     ap.add_argument("--sharded-c5-size", type=int, default=16384, help="M = N of the row-sharded LP measured beside the replicas when N > 1")
     ap.add_argument("--sharded-c5-timeout", type=float, default=420.0, help="seconds the children of that measurement get")
@@ -356,7 +359,8 @@ def sharded_c5_in_children(args, dist, rank, local_rank, world):
         rec = json.loads(line[-1])
         return {"value": rec["value"], "unit": rec["unit"], "us_per_pivot": rec["roofline"]["us_per_pivot"], "n_gpus": rec["n_gpus"],
                 "scaling": rec["scaling"], "workload": rec["config"]["workload"], "exchange": rec["config"]["exchange"],
-                "roofline": rec["roofline"], "rehearsal": rec.get("rehearsal"), "wall_s": time.perf_counter() - t0}
+                "roofline": rec["roofline"], "parity": rec.get("parity"), "cpu_baseline": rec.get("cpu_baseline"), "rehearsal": rec.get("rehearsal"),
+                "wall_s": time.perf_counter() - t0}
     except Exception as e:  # noqa: BLE001 -- by contract nothing here may change the headline or the return code
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
@@ -395,6 +399,7 @@ def bench_sharded(args, torch, dist, rank, local_rank, world):
 
     run(args.pivots_per_step * max(args.warmup, 1))
     dt, npiv, status, gpu_ms, info = run(args.pivots_per_step * args.steps)
+    verdict = verify_sharded(args, torch, dist, sharded, local, w, h, M, N, bounds, ident, rank, local_rank, world, rehearsal) if args.verify_pivots > 0 else None
     t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -429,11 +434,59 @@ def bench_sharded(args, torch, dist, rank, local_rank, world):
                           "figure is kept as algorithmic_equiv" % depth)
         rf_kernel = info["kernel"]
         out["roofline"]["kernel"] = rf_kernel
+        if verdict is not None:
+            out["cpu_baseline"], out["parity"] = verdict
         if rehearsal:
             out["rehearsal"] = "ranks share GPU 0 (fewer GPUs than ranks): host transport over gloo, control-flow check only"
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def verify_sharded(args, torch, dist, sharded, local, w, h, M, N, bounds, ident, rank, local_rank, world, rehearsal):
+    """The first pivots of the same LP once more, every rank's rows hashed (SHA-256 per 512 rows) and compared on rank 0 with the
+    CPU oracle's tableau after the same pivots -- the oracle run is timed and doubles as this workload's cpu_baseline (row loop of
+    the elimination over --cpu-threads threads).  Returns (cpu_baseline, parity) on rank 0, None elsewhere; never raises."""
+    import hashlib
+    try:
+        K = args.verify_pivots
+        ops = sharded.HipShardOps(local, w, bounds, rank, h, ident, ident.copy(), device=local_rank, private_stream=True)
+        comm = sharded.native_comm(ops.ctx, rank, world, transport="host" if rehearsal else "rccl")
+        status, result, npiv, _ = ops.run_native(comm, max_pivots=float(K), check_every=16)
+        lm, pos, var = ops.download()
+        comm.close()
+        ops.close()
+        lm = lm.reshape(-1, w)
+        mine = [(0, 1, hashlib.sha256(lm[0].tobytes()).hexdigest())]
+        for lo in range(0, lm.shape[0] - 1, 512):
+            blk = np.ascontiguousarray(lm[1 + lo:1 + lo + 512])
+            mine.append((bounds[rank] + lo, bounds[rank] + lo + blk.shape[0], hashlib.sha256(blk.tobytes()).hexdigest()))
+        del lm
+        parts = [mine]
+        if dist is not None:
+            parts = [None] * world
+            dist.all_gather_object(parts, mine)
+        if rank != 0:
+            return None
+        from tests import _oracle  # (the checker: CPU restatement of the reference, pinned by its golden records)
+        threads = max(1, min(args.cpu_threads if args.cpu_threads > 0 else 1, os.cpu_count() or 1))
+        orc = _oracle.load(omp=threads > 1)
+        cores = orc.set_threads(threads) if threads > 1 else 1
+        ref = orc.dense_lp(M, N, 42)
+        rpos, rvar = ident.copy(), ident.copy()
+        t0 = time.perf_counter()
+        est, eres, epiv, _ = orc.simplex(ref, w, h, rpos, rvar, max_pivots=float(K))
+        dt = time.perf_counter() - t0
+        ref = ref.reshape(h, w)
+        bad = [(lo, hi) for p in parts for lo, hi, sha in p if hashlib.sha256(np.ascontiguousarray(ref[lo:hi]).tobytes()).hexdigest() != sha]
+        ok = not bad and (status, npiv) == (est, epiv) and np.array_equal(pos, rpos) and np.array_equal(var, rvar)
+        cpu = {"value": epiv / dt, "unit": "pivots/s", "cores": cores, "kind": "port",
+               "sample": "%d pivots of the same dense-LP(%d,%d,seed=42), oracle/simplex_oracle.c%s, %.1f s" % (epiv, M, N, " -fopenmp, %d threads" % cores if threads > 1 else "", dt)}
+        parity = {"ok": bool(ok), "pivots": int(npiv), "blocks_checked": sum(len(p) for p in parts), "blocks_wrong": bad[:8], "status": [status, est],
+                  "what": "every rank's rows after %d pivots (SHA-256 per 512 rows), both permutations, status and pivot count against the CPU oracle" % K}
+        return cpu, parity
+    except Exception as e:  # noqa: BLE001 -- a failed check is reported, the measurement above stands
+        return ({"value": None, "unit": "pivots/s", "cores": 0, "kind": "port", "sample": "failed"}, {"ok": False, "error": "%s: %s" % (type(e).__name__, e)}) if rank == 0 else None
 
 
 if __name__ == "__main__":

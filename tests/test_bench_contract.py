@@ -47,6 +47,7 @@ def test_sharded_workload_line(extra, kernel):
         assert k in rec, k
     assert rec["scaling"] == "strong" and rec["value"] > 0
     assert rec["roofline"]["kernel"].startswith(kernel), rec["roofline"]
+    assert rec["parity"]["ok"] is True and rec["parity"]["pivots"] == 48 and rec["cpu_baseline"]["value"] > 0, rec["parity"]
     if kernel == "dshard_kernel":
         assert rec["roofline"]["delay_depth"] == 8 and "algorithmic_equiv" in rec["roofline"]
 
@@ -79,7 +80,7 @@ def test_two_ranks_line_carries_the_row_sharded_measurement():
     assert "error" not in c5, c5
     assert c5["n_gpus"] == 2 and c5["scaling"] == "strong" and c5["value"] > 0 and c5["us_per_pivot"] > 0
     assert c5["roofline"]["kernel"].startswith("dshard_kernel") and c5["exchange"]["transport"] == "host"
-    assert "4097x4097" in c5["workload"]
+    assert "4097x4097" in c5["workload"] and c5["parity"]["ok"] is True, c5.get("parity")
 
 
 @pytest.mark.gpu

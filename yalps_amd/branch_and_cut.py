@@ -254,7 +254,7 @@ def branch_and_cut_device(tabmod, root, node, init_result, options, stats=None):
     timedout = now() >= stop_time
     solution_found, best_eval, best_tableau, it = False, math.inf, tableau, 0
     if stats is not None:
-        stats.update(device_nodes=0, pivots=0)
+        stats.update(device_nodes=0)  # (no pivot count on this path: yalps_tableau_node_solve returns status, result, column 0 and the basis only)
     while it < max_iterations and branches and best_eval >= optimal_threshold and not timedout:
         br = heapq.heappop(branches)
         relaxed_eval, cuts = br.eval, br.cuts
