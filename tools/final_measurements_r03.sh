@@ -31,8 +31,8 @@ for rows in 0 8192 4096 2048; do
   r=$( [ $rows = 0 ] && echo "" || echo "--shard-rows $rows" ); tag=$( [ $rows = 0 ] && echo 16385 || echo $(( rows + 1 )) )
   python3 bench.py --workload sharded --size 16384 $r --steps 3 --warmup 1 --pivots-per-step 256 2> /dev/null | grep "^{" > $out/shard_${tag}x16385.json
 done
-prof shard_2049x16385_prof dshard -- python3 bench.py --workload sharded --size 16384 --shard-rows 2048 --steps 2 --warmup 1 --pivots-per-step 256
-prof shard_16385x16385_prof dshard -- python3 bench.py --workload sharded --size 16384 --steps 1 --warmup 1 --pivots-per-step 256
+prof shard_2049x16385_prof dshard -- python3 bench.py --workload sharded --size 16384 --shard-rows 2048 --steps 2 --warmup 1 --pivots-per-step 256 --verify-pivots 0
+prof shard_16385x16385_prof dshard -- python3 bench.py --workload sharded --size 16384 --steps 1 --warmup 1 --pivots-per-step 256 --verify-pivots 0
 echo "=== shards done"
 python3 tools/delayed_stages.py --kernel stream3 --size 16384 --pivots 480 --out $out/stream3_stages_16384.json > /dev/null 2>&1
 python3 tools/delayed_stages.py --kernel stream3 --size 8192 --pivots 800 --out $out/stream3_stages_8192.json > /dev/null 2>&1
