@@ -149,15 +149,33 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
         __syncthreads();
     };
     // every touched row of mine streamed once, all pending eliminations in registers; afterwards nothing is pending
-    auto flush_pending = [&]() __attribute__((always_inline)) {
+    // (the objective row is not swept: workgroup 0 copies the replica -- `obj_now`, the same arithmetic pivot by pivot -- over it; with it the
+    // first workgroup had one row more than the others wherever a rank holds 2^k rows: a fifth trip of 8 waves x 2 rows per panel for ONE row)
+    auto flush_pending = [&](const double *obj_now) __attribute__((always_inline)) {
         if (npend == 0) return; // (uniform)
+        if (b == 0) {
+            const __amdgpu_buffer_rsrc_t rs_o = rsrc_of(obj_now), rs_0 = rsrc_of(mat);
+#pragma unroll 1
+            for (int jb = 0; jb < J; jb += 4) {
+                double2 o[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (jb + j < J) o[j] = row_ld16<AUX_PLAIN>(rs_o, lane_off + 16 * T * (jb + j), 0); // (its lanes' own stores where this launch wrote it: in order)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (jb + j < J) row_st16<NT ? AUX_NT : AUX_PLAIN>(rs_0, lane_off + 16 * T * (jb + j), 0, o[j]);
+            }
+        }
         if (tid < 64) {         // compact list of my touched rows (wave 0)
             int cnt = 0;
             for (int base = 0; base < my_rows; base += 64) {
                 const int i = base + tid;
                 bool t = false;
-                if (i < my_rows)
-                    for (int p = 0; p < npend; p++) t = t || i == sh_pl[p] || fabs(colv0[p * rpw + i]) > 1e-16;
+                if (i < my_rows && b + i > 0) // (not the objective row)
+                    {
+#pragma unroll 4
+                    for (int p = 0; p < npend; p++) t = t | (i == sh_pl[p]) | (fabs(colv0[p * rpw + i]) > 1e-16); // (no short circuit: the LDS reads of four pending pivots in flight, not a chain of round trips)
+                }
                 const unsigned long long m = __ballot(t);
                 if (t) tlist[cnt + __popcll(m & ((1ull << tid) - 1ull))] = i;
                 cnt += __popcll(m);
@@ -295,7 +313,7 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
     if (term == RUNNING && check && d.cyc_verdict[parity & 1]) term = YALPS_CYCLED; // :98,137: shard_cycle_kernel's verdict on this pivot
     YSTAMP(1); // decide (the gathered records, phase 1: the entering column)
     if (term != RUNNING) { // the solve ends here: the pending pivots are carried out on the way out
-        flush_pending();
+        flush_pending(objA);
         if (b == 0 && tid == 0) {
             write_state(term, phase, la_in, pbuf, 0, 0, 0, (phase_switched ? 0 : hist_len_in) + (term == YALPS_CYCLED ? check : 0), iter, term_result, pivots_in);
             DelayState z = {};
@@ -463,7 +481,7 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
         *Dout = o;
     }
     YSTAMP(8); // state
-    if (npend == depth) flush_pending();
+    if (npend == depth) flush_pending(objB);
     YSTAMP(9); // the sweep (every depth-th launch)
 #ifdef YALPS_STAMPS
     if (tid == 0 && d.dbg) {

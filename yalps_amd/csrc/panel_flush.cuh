@@ -22,7 +22,7 @@
 // were and what replaces them; pl[p] = my slot of pending pivot p's pivot row or -1, pc[p] = its pivot column (mat index);
 // tlist[0 .. nt) = my row slots touched by at least one pending pivot.  Rows and pending rows are addressed through buffer
 // descriptors of one row (rsrc_of): units past the pitch read as 0.0 and their stores are dropped.
-template <int T, int PU, int LU, int D, int SETS, bool NT, typename RsrcOf>
+template <int T, int PU, int LU, int D, int SETS, bool NT, int CH = 8, typename RsrcOf>
 __device__ __forceinline__ void panel_flush(double *mat, int pitch, int b, int NB, const double *pend0, int npend, const double *colv,
                                             const double *nqv, int rpw, const int *pl, const int *pc, const int *tlist, int nt, double *panel,
                                             RsrcOf rsrc_of) {
@@ -35,6 +35,7 @@ __device__ __forceinline__ void panel_flush(double *mat, int pitch, int b, int N
     constexpr int RS = T / LU; // rows side by side
     constexpr int U = PU / LU; // units per lane and row
     constexpr int AUX = NT ? AUX_NT : AUX_PLAIN;
+    __shared__ unsigned sh_slow[T / 64]; // per wave of the fill: pending rows with a flushed entry among the units it copied
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid)); // (opaque: the lane's LDS and row offsets are recomputed here, not hoisted out of the caller's pivot loop and kept -- or spilled -- there)
     const int sub = tid / LU, lane = tid % LU;
@@ -42,23 +43,50 @@ __device__ __forceinline__ void panel_flush(double *mat, int pitch, int b, int N
     for (int pnl = 0; pnl < npanel; pnl++) {
         const int u0 = pnl * PU;
         __syncthreads(); // (everybody is through with the previous panel -- and, the first time, with whatever used this LDS before)
-        for (int i = tid; i < npend * PU; i += T) { // (a wave's 64 units belong to one pending row: PU is a multiple of 64)
-            const int p = i / PU, u = i - p * PU;
-            const double2 v = row_ld16<AUX_PLAIN>(rsrc_of(pend0 + (size_t)p * pitch), 16 * (u0 + u), 0);
-            *reinterpret_cast<double2 *>(panel + (size_t)p * 2 * PU + 2 * u) = v;
+        // The fill: CH loads of a lane in flight behind one wait (a load, its wait, its LDS store, per pending row, was a chain of
+        // npend L2 round trips per panel -- with the test for flushed entries below, a chain of LDS round trips per unit, it
+        // made a pending pivot cost a sweep of 4097^2 5.4 us where its arithmetic is 0.9).  One descriptor over all pending rows
+        // (a row per load through the instruction's scalar offset does not work: gfx950 range-checks it against the row's length).
+        // Per wave and pending row: was any of the 64 units this wave copied flushed (src/simplex.ts:17-24)?  OR-ed over the
+        // waves behind the barrier: nothing of this panel's slice of a pending pivot row was flushed -> the select-free path
+        // (:31's inner loop as two fp64 instructions per element).
+        {
+            // (CH: pending rows' loads of a lane in flight at once)
+            const int items = npend * PU, row_bytes = pitch * 8;
+            const unsigned long long pa0 = reinterpret_cast<unsigned long long>(pend0); // (uniform: into scalar registers)
+            const unsigned long long pau = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pa0 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)pa0);
+            const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<double *>(pau), 0, __builtin_amdgcn_readfirstlane(npend * row_bytes), 0x00020000);
+            unsigned slow = 0;
+#pragma unroll 1
+            for (int i0 = 0; i0 < items; i0 += CH * T) {
+                double2 v[CH];
+#pragma unroll
+                for (int k = 0; k < CH; k++) {
+                    const int i = i0 + k * T + tid; // (a wave's 64 units belong to one pending row: PU is a multiple of 64)
+                    const int pp = __builtin_amdgcn_readfirstlane(i / PU);
+                    const int un = u0 + i - pp * PU; // the unit within its row; past the pitch: 0.0, as a row's own descriptor returns it
+                    if (i < items) v[k] = un < units ? row_ld16<AUX_PLAIN>(rs0, pp * row_bytes + 16 * un, 0) : double2{0.0, 0.0};
+                }
+#pragma unroll
+                for (int k = 0; k < CH; k++) {
+                    const int i = i0 + k * T + tid;
+                    const int pp = __builtin_amdgcn_readfirstlane(i / PU);
+                    if (i < items) {
+                        *reinterpret_cast<double2 *>(panel + (size_t)pp * 2 * PU + 2 * (i - pp * PU)) = v[k];
+                        const bool fl = (unsigned long long)__double_as_longlong(v[k].x) == FLUSHED || (unsigned long long)__double_as_longlong(v[k].y) == FLUSHED;
+                        if (__builtin_amdgcn_ballot_w64(fl) != 0) slow |= 1u << pp;
+                    }
+                }
+            }
+            if ((tid & 63) == 0) sh_slow[tid >> 6] = slow;
         }
         __syncthreads();
-        // per wave and pending pivot: nothing of my lanes' units was flushed -> the select-free path (:31's inner loop as two
-        // fp64 instructions per element); the pivot-column patch of this panel, if the column lies in it
         unsigned fastmask = 0;
-        for (int p = 0; p < npend; p++) {
-            bool fl = false;
+        {
+            unsigned slow = 0;
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const double2 pn = *reinterpret_cast<const double2 *>(panel + (size_t)p * 2 * PU + 2 * (lane + u * LU));
-                fl = fl || (unsigned long long)__double_as_longlong(pn.x) == FLUSHED || (unsigned long long)__double_as_longlong(pn.y) == FLUSHED;
-            }
-            if (__builtin_amdgcn_ballot_w64(fl) == 0) fastmask |= 1u << p;
+            for (int w = 0; w < T / 64; w++) slow |= sh_slow[w];
+            fastmask = ~slow;
         }
         // Two sets of D rows in flight per lane, A and B: the loads of both are issued before A is worked on, and by the time a
         // set's registers are loaded again its stores -- issued a whole set earlier -- have left.  (One set: the next batch's loads
@@ -76,69 +104,105 @@ __device__ __forceinline__ void panel_flush(double *mat, int pitch, int b, int N
             }
         };
         auto apply_set = [&](double2 (&x)[D][U], const int (&ri)[D]) __attribute__((always_inline)) {
-            // Everything a pending pivot needs from LDS -- its panel units, its column and pivot-row slot, my rows' coefficients --
-            // is read unconditionally at the top of its turn: ONE LDS latency per pending pivot and set (a read followed by the
-            // branch that depends on it, row after row, is a chain of LDS round trips).
-#pragma unroll 1
-            for (int p = 0; p < npend; p++) {
-                constexpr int UH = U > 4 ? 4 : U; // units of the pending row in registers at a time
-                double cf_c[D];
+            // The LDS reads of a pending pivot run ONE HALF AHEAD of the arithmetic: while the units [0, UH) of pending pivot p are
+            // worked on, its units [UH, U) are on their way; while those are worked on, pivot p + 1's first half and its scalars
+            // (my rows' coefficients, its column, its pivot-row slot).  All waves of a workgroup walk the pending pivots in step
+            // behind the panel's barrier, so a read followed by the arithmetic that needs it was an LDS round trip nobody
+            // covered -- twice per pending pivot: at 4097^2 a pending pivot cost a sweep 5.4 us where its arithmetic is 0.9.
+            constexpr int UH = U > 4 ? U / 2 : U, NH = U / UH; // units of the pending row per half
+            int rsl[D];
 #pragma unroll
-                for (int d = 0; d < D; d++) cf_c[d] = colv[p * rpw + (ri[d] < 0 ? r_any : ri[d])];
-                const int colxp = pc[p], lslotp = pl[p];
+            for (int d = 0; d < D; d++) rsl[d] = ri[d] < 0 ? r_any : ri[d];
+            const double *pan = panel + 2 * lane;
+            auto rd_units = [&](int p, int ub, double2 (&pn)[UH]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int u = 0; u < UH; u++) pn[u] = *reinterpret_cast<const double2 *>(pan + (size_t)p * 2 * PU + 2 * (ub + u) * LU);
+            };
+            auto rd_hdr = [&](int p, double (&cf)[D], int &colx, int &lslot) __attribute__((always_inline)) {
+#pragma unroll
+                for (int d = 0; d < D; d++) cf[d] = colv[p * rpw + rsl[d]];
+                colx = pc[p];
+                lslot = pl[p];
+            };
+            auto work = [&](int p, const double (&cf_c)[D], int colxp, int lslotp, int ub, const double2 (&pn_c)[UH]) __attribute__((always_inline)) {
                 const bool fastp = (fastmask >> p) & 1u;
                 const int pcu = (colxp >> 1) - u0; // the pivot column's unit within this panel (uniform; in range or not)
                 const bool col_here = (unsigned)pcu < (unsigned)PU;
 #pragma unroll
-                for (int ub = 0; ub < U; ub += UH) {
-                    double2 pn_c[UH];
+                for (int d = 0; d < D; d++) {
+                    const double coef = cf_c[d];
+                    const bool piv = ri[d] == lslotp;
+                    if (ri[d] < 0 || !(piv || fabs(coef) > 1e-16)) continue; // (uniform per wave) :31
+                    if (fastp && !piv) { // (uniform) nothing of this panel's slice of the pivot row was flushed: two instructions per element
 #pragma unroll
-                    for (int u = 0; u < UH; u++) pn_c[u] = *reinterpret_cast<const double2 *>(panel + (size_t)p * 2 * PU + 2 * (lane + (ub + u) * LU));
-                    __builtin_amdgcn_sched_barrier(0); // (the reads above stay together, in front of the arithmetic)
-#pragma unroll
-                    for (int d = 0; d < D; d++) {
-                        const double coef = cf_c[d];
-                        const bool piv = ri[d] == lslotp;
-                        if (ri[d] < 0 || !(piv || fabs(coef) > 1e-16)) continue; // (uniform per wave) :31
-                        if (fastp && !piv) { // (uniform) nothing of this panel's slice of the pivot row was flushed: two instructions per element
-#pragma unroll
-                            for (int u = 0; u < UH; u++) {
-                                double2 &xv = x[d][ub + u];
-                                const double px = coef * pn_c[u].x, py = coef * pn_c[u].y;
-                                xv.x = xv.x - px;
-                                xv.y = xv.y - py;
-                            }
-                        } else {
-#pragma unroll
-                            for (int u = 0; u < UH; u++) {
-                                double2 &xv = x[d][ub + u];
-                                const double2 pn = pn_c[u];
-                                const bool f0 = (unsigned long long)__double_as_longlong(pn.x) != FLUSHED;
-                                const bool f1 = (unsigned long long)__double_as_longlong(pn.y) != FLUSHED;
-                                if (piv) {
-                                    xv.x = f0 ? pn.x : 0.0;
-                                    xv.y = f1 ? pn.y : 0.0;
-                                } else {
-                                    const double px = coef * pn.x, py = coef * pn.y;
-                                    const double nx = xv.x - px, ny = xv.y - py;
-                                    xv.x = f0 ? nx : xv.x;
-                                    xv.y = f1 ? ny : xv.y;
-                                }
-                            }
+                        for (int u = 0; u < UH; u++) {
+                            double2 &xv = x[d][ub + u];
+                            const double px = coef * pn_c[u].x, py = coef * pn_c[u].y;
+                            xv.x = xv.x - px;
+                            xv.y = xv.y - py;
                         }
-                        if (col_here) { // (uniform; one panel in npanel) :25, :36 -- the one element of the row that the pivot column replaces
-                            const double patch = nqv[p * rpw + ri[d]];
+                    } else {
 #pragma unroll
-                            for (int u = 0; u < UH; u++)
-                                if (pcu == lane + (ub + u) * LU) {
-                                    if (colxp & 1)
-                                        x[d][ub + u].y = patch;
-                                    else
-                                        x[d][ub + u].x = patch;
-                                }
+                        for (int u = 0; u < UH; u++) {
+                            double2 &xv = x[d][ub + u];
+                            const double2 pn = pn_c[u];
+                            const bool f0 = (unsigned long long)__double_as_longlong(pn.x) != FLUSHED;
+                            const bool f1 = (unsigned long long)__double_as_longlong(pn.y) != FLUSHED;
+                            if (piv) {
+                                xv.x = f0 ? pn.x : 0.0;
+                                xv.y = f1 ? pn.y : 0.0;
+                            } else {
+                                const double px = coef * pn.x, py = coef * pn.y;
+                                const double nx = xv.x - px, ny = xv.y - py;
+                                xv.x = f0 ? nx : xv.x;
+                                xv.y = f1 ? ny : xv.y;
+                            }
                         }
                     }
+                    if (col_here) { // (uniform; one panel in npanel) :25, :36 -- the one element of the row that the pivot column replaces
+                        const double patch = nqv[p * rpw + ri[d]];
+#pragma unroll
+                        for (int u = 0; u < UH; u++)
+                            if (pcu == lane + (ub + u) * LU) {
+                                if (colxp & 1)
+                                    x[d][ub + u].y = patch;
+                                else
+                                    x[d][ub + u].x = patch;
+                            }
+                    }
                 }
+            };
+            double cfa[D], cfb[D];
+            int cola, slota, colb, slotb;
+            double2 pa[UH], pb[UH];
+            rd_hdr(0, cfa, cola, slota);
+            rd_units(0, 0, pa);
+#pragma unroll 1
+            for (int p = 0; p < npend; p++) {
+                const int pnx = p + 1 < npend ? p + 1 : p; // (the last turn reads its own pivot again: nobody uses it)
+                if constexpr (NH == 2) {
+                    rd_units(p, UH, pb);
+                    __builtin_amdgcn_sched_barrier(0); // (the reads stay in front of the arithmetic they run ahead of)
+                    work(p, cfa, cola, slota, 0, pa);
+                    __builtin_amdgcn_sched_barrier(0);
+                    rd_hdr(pnx, cfb, colb, slotb);
+                    rd_units(pnx, 0, pa);
+                    __builtin_amdgcn_sched_barrier(0);
+                    work(p, cfa, cola, slota, UH, pb);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    rd_hdr(pnx, cfb, colb, slotb);
+                    rd_units(pnx, 0, pb);
+                    __builtin_amdgcn_sched_barrier(0);
+                    work(p, cfa, cola, slota, 0, pa);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < UH; u++) pa[u] = pb[u];
+                }
+#pragma unroll
+                for (int d = 0; d < D; d++) cfa[d] = cfb[d];
+                cola = colb;
+                slota = slotb;
             }
         };
         auto store_set = [&](const double2 (&x)[D][U], const int (&ri)[D]) __attribute__((always_inline)) {

@@ -843,7 +843,7 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
                 t->sshmem2 = lds3;
                 d.delay_depth = depth3;
                 HIP_TRY(hipMalloc(&d.pend, sizeof(double) * 8 * 2 * (size_t)depth3 * d.pitch)); // (per XCD: two sets of `depth` rows, shared by its workgroups)
-                if (sJ > 8) HIP_TRY(hipMalloc(&d.ob_park, sizeof(double) * (size_t)t->nb * d.pitch)); // (16-unit rows: the objective replicas during a sweep)
+                if (sJ >= 6) HIP_TRY(hipMalloc(&d.ob_park, sizeof(double) * (size_t)t->nb * d.pitch)); // (rows of 6+ units per lane: the objective replicas during a sweep)
                 t->stream3 = true;
             }
         }
