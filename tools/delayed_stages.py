@@ -41,6 +41,8 @@ STAGES = {
         8: "my candidate (arg-min) + key record",
         9: "basis bookkeeping (workgroup 0)",
         10: "the sweep (every depth-th pivot) / barrier",
+        18: "sweep: barrier in front of the fill (the other waves' trips)", 11: "sweep: panel fill (L2 -> LDS)", 12: "sweep: barrier behind the fill / between trips", 13: "sweep: my rows' loads (waited for here in this build)",
+        14: "sweep: the pending pivots applied in registers", 15: "sweep: stores issued", 16: "sweep: tail units", 17: "sweep: last barrier",
     },
     "dshard": {
         0: "state + the pending pivots' scalars of my rows -> LDS (launch prologue)",
@@ -53,6 +55,8 @@ STAGES = {
         7: "my candidates, two arg-mins, the partials",
         8: "state",
         9: "the sweep (every depth-th launch)",
+        18: "sweep: barrier in front of the fill (the other waves' trips)", 11: "sweep: panel fill (L2 -> LDS)", 12: "sweep: barrier behind the fill / between trips", 13: "sweep: my rows' loads (waited for here in this build)",
+        14: "sweep: the pending pivots applied in registers", 15: "sweep: stores issued", 16: "sweep: tail units", 17: "sweep: last barrier",
     },
 }
 

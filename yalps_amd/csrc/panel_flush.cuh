@@ -3,6 +3,13 @@
 // one column PANEL at a time.
 // Part of libyalps_hip.so; included by persistent_stream3.hip / persistent_dshard.hip inside their unnamed namespaces.
 #pragma once
+#ifdef YALPS_STAMPS // (diagnostic build: the callers' stage sums continue inside the sweep, stages 11-17)
+#define YSTAMP_PARAMS , unsigned long long (&st_acc)[20], unsigned long long &st_last
+#define YSTAMP_ARGS , st_acc, st_last
+#else
+#define YSTAMP_PARAMS
+#define YSTAMP_ARGS
+#endif
 
 // Round 2 read the pending rows from L2 for every two to four (half-)rows in flight: with 8 pending pivots that is 2-4 x the
 // rows' own traffic through the L2s, and eight dependent L2 round trips per batch -- 16385^2 swept at 4.6 TB/s where the
@@ -25,7 +32,7 @@
 template <int T, int PU, int LU, int D, int SETS, bool NT, int CH = 8, typename RsrcOf>
 __device__ __forceinline__ void panel_flush(double *mat, int pitch, int b, int NB, const double *pend0, int npend, const double *colv,
                                             const double *nqv, int rpw, const int *pl, const int *pc, const int *tlist, int nt, double *panel,
-                                            RsrcOf rsrc_of) {
+                                            RsrcOf rsrc_of YSTAMP_PARAMS) {
     // LU lanes across a row segment of PU units: U = PU / LU units per lane and row, RS = T / LU rows side by side.  One WAVE per
     // row (LU = 64, eight units per lane) is what keeps the sweep off the vector ALU: what a pending pivot costs a row apart
     // from its elements -- coefficient, skip test (:31), pivot-row and pivot-column tests, branches: ~25 instructions -- is
@@ -39,10 +46,16 @@ __device__ __forceinline__ void panel_flush(double *mat, int pitch, int b, int N
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid)); // (opaque: the lane's LDS and row offsets are recomputed here, not hoisted out of the caller's pivot loop and kept -- or spilled -- there)
     const int sub = tid / LU, lane = tid % LU;
-    const int units = pitch >> 1, npanel = (units + PU - 1) / PU;
+    // A row of 2^k + 1 columns (every BASELINE configuration) is k' full panels and ONE more unit: a whole panel pass -- fill, two
+    // barriers, every wave's trips through the pending pivots -- for 16 bytes of every row.  Up to TAIL units behind the last full
+    // panel go through tail_units() below instead: a lane per (row, unit), the pending rows' units straight from L2.
+    constexpr int TAIL = 64;
+    const int units = pitch >> 1, rem = units % PU, ntail = (units > PU && rem <= TAIL) ? rem : 0;
+    const int npanel = (units - ntail + PU - 1) / PU;
     for (int pnl = 0; pnl < npanel; pnl++) {
         const int u0 = pnl * PU;
         __syncthreads(); // (everybody is through with the previous panel -- and, the first time, with whatever used this LDS before)
+        YSTAMP(18); // sweep: barrier in front of the fill (the other waves' trips)
         // The fill: CH loads of a lane in flight behind one wait (a load, its wait, its LDS store, per pending row, was a chain of
         // npend L2 round trips per panel -- with the test for flushed entries below, a chain of LDS round trips per unit, it
         // made a pending pivot cost a sweep of 4097^2 5.4 us where its arithmetic is 0.9).  One descriptor over all pending rows
@@ -80,6 +93,7 @@ __device__ __forceinline__ void panel_flush(double *mat, int pitch, int b, int N
             }
             if ((tid & 63) == 0) sh_slow[tid >> 6] = slow;
         }
+        YSTAMP(11); // sweep: panel fill
         __syncthreads();
         unsigned fastmask = 0;
         {
@@ -87,6 +101,12 @@ __device__ __forceinline__ void panel_flush(double *mat, int pitch, int b, int N
 #pragma unroll
             for (int w = 0; w < T / 64; w++) slow |= sh_slow[w];
             fastmask = ~slow;
+        }
+        // pending pivots whose pivot column lies in this panel (one panel in npanel per pending pivot): they patch an element (:25, :36)
+        unsigned colmask = 0;
+        for (int p = 0; p < npend; p++) {
+            const int pcu = (__builtin_amdgcn_readfirstlane(pc[p]) >> 1) - u0;
+            if ((unsigned)pcu < (unsigned)PU) colmask |= 1u << p;
         }
         // Two sets of D rows in flight per lane, A and B: the loads of both are issued before A is worked on, and by the time a
         // set's registers are loaded again its stores -- issued a whole set earlier -- have left.  (One set: the next batch's loads
@@ -118,13 +138,12 @@ __device__ __forceinline__ void panel_flush(double *mat, int pitch, int b, int N
 #pragma unroll
                 for (int u = 0; u < UH; u++) pn[u] = *reinterpret_cast<const double2 *>(pan + (size_t)p * 2 * PU + 2 * (ub + u) * LU);
             };
-            auto rd_hdr = [&](int p, double (&cf)[D], int &colx, int &lslot) __attribute__((always_inline)) {
+            auto rd_hdr = [&](int p, double (&cf)[D]) __attribute__((always_inline)) {
 #pragma unroll
                 for (int d = 0; d < D; d++) cf[d] = colv[p * rpw + rsl[d]];
-                colx = pc[p];
-                lslot = pl[p];
             };
-            auto work = [&](int p, const double (&cf_c)[D], int colxp, int lslotp, int ub, const double2 (&pn_c)[UH]) __attribute__((always_inline)) {
+            auto work = [&](int p, const double (&cf_c)[D], int ub, const double2 (&pn_c)[UH]) __attribute__((always_inline)) {
+                const int colxp = pc[p], lslotp = pl[p]; // (the rare path reads them where it needs them)
                 const bool fastp = (fastmask >> p) & 1u;
                 const int pcu = (colxp >> 1) - u0; // the pivot column's unit within this panel (uniform; in range or not)
                 const bool col_here = (unsigned)pcu < (unsigned)PU;
@@ -172,37 +191,78 @@ __device__ __forceinline__ void panel_flush(double *mat, int pitch, int b, int N
                     }
                 }
             };
+            // The usual pending pivot -- nothing of its row flushed in this panel, its column elsewhere, all my rows in flight touched
+            // and none of them its pivot row -- is decided ONCE per trip from scalar bit masks and runs as straight-line code: two
+            // fp64 instructions per element behind one scalar branch (the tests, row by row and half by half, were a third of a
+            // pending pivot's instructions).  Everything else takes work() as before.
+            unsigned plain = fastmask & ~colmask;
+            {
+#pragma unroll 1
+                for (int p0 = 0; p0 < npend; p0 += 2) {
+                    double c2[2][D];
+                    int s2[2];
+#pragma unroll
+                    for (int q = 0; q < 2; q++) { // (the LDS reads of two pending pivots in flight)
+                        const int p = p0 + q < npend ? p0 + q : p0;
+#pragma unroll
+                        for (int d = 0; d < D; d++) c2[q][d] = colv[p * rpw + rsl[d]];
+                        s2[q] = pl[p];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        bool ok = true;
+#pragma unroll
+                        for (int d = 0; d < D; d++) ok = ok && ri[d] >= 0 && ri[d] != s2[q] && fabs(c2[q][d]) > 1e-16;
+                        if (__builtin_amdgcn_ballot_w64(ok) != ~0ull) plain &= ~(1u << (p0 + q)); // (uniform per wave anyway)
+                    }
+                }
+            }
+            auto straight = [&](const double (&cf_c)[D], int ub, const double2 (&pn_c)[UH]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int d = 0; d < D; d++)
+#pragma unroll
+                    for (int u = 0; u < UH; u++) {
+                        double2 &xv = x[d][ub + u];
+                        const double px = cf_c[d] * pn_c[u].x, py = cf_c[d] * pn_c[u].y;
+                        xv.x = xv.x - px;
+                        xv.y = xv.y - py;
+                    }
+            };
             double cfa[D], cfb[D];
-            int cola, slota, colb, slotb;
             double2 pa[UH], pb[UH];
-            rd_hdr(0, cfa, cola, slota);
+            rd_hdr(0, cfa);
             rd_units(0, 0, pa);
 #pragma unroll 1
             for (int p = 0; p < npend; p++) {
                 const int pnx = p + 1 < npend ? p + 1 : p; // (the last turn reads its own pivot again: nobody uses it)
+                const bool is_plain = (plain >> p) & 1u;   // (scalar)
                 if constexpr (NH == 2) {
                     rd_units(p, UH, pb);
                     __builtin_amdgcn_sched_barrier(0); // (the reads stay in front of the arithmetic they run ahead of)
-                    work(p, cfa, cola, slota, 0, pa);
+                    if (is_plain)
+                        straight(cfa, 0, pa);
+                    else
+                        work(p, cfa, 0, pa);
                     __builtin_amdgcn_sched_barrier(0);
-                    rd_hdr(pnx, cfb, colb, slotb);
+                    rd_hdr(pnx, cfb);
                     rd_units(pnx, 0, pa);
                     __builtin_amdgcn_sched_barrier(0);
-                    work(p, cfa, cola, slota, UH, pb);
+                    if (is_plain)
+                        straight(cfa, UH, pb);
+                    else
+                        work(p, cfa, UH, pb);
                     __builtin_amdgcn_sched_barrier(0);
                 } else {
-                    rd_hdr(pnx, cfb, colb, slotb);
+                    rd_hdr(pnx, cfb);
                     rd_units(pnx, 0, pb);
                     __builtin_amdgcn_sched_barrier(0);
-                    work(p, cfa, cola, slota, 0, pa);
+                    work(p, cfa, 0, pa);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int u = 0; u < UH; u++) pa[u] = pb[u];
                 }
 #pragma unroll
                 for (int d = 0; d < D; d++) cfa[d] = cfb[d];
-                cola = colb;
-                slota = slotb;
             }
         };
         auto store_set = [&](const double2 (&x)[D][U], const int (&ri)[D]) __attribute__((always_inline)) {
@@ -219,17 +279,72 @@ __device__ __forceinline__ void panel_flush(double *mat, int pitch, int b, int N
         for (int k0 = 0; k0 < nt; k0 += SETS * RS * D) {
             double2 xa[D][U], xb[SETS == 2 ? D : 1][U];
             int ria[D], rib[SETS == 2 ? D : 1];
+            YSTAMP(12); // sweep: barrier behind the fill, flags / between trips
             load_set(k0, xa, ria);
             if constexpr (SETS == 2) load_set(k0 + RS * D, xb, rib);
+#ifdef YALPS_STAMPS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            YSTAMP(13); // sweep: my rows' loads (diagnostic build waits for them here)
             apply_set(xa, ria);
+            YSTAMP(14); // sweep: the pending pivots applied in registers
             store_set(xa, ria);
+            YSTAMP(15); // sweep: stores issued
             if constexpr (SETS == 2) {
                 apply_set(xb, rib);
                 store_set(xb, rib);
             }
         }
     }
+    if (ntail > 0) { // (uniform)
+        const int ut0 = npanel * PU; // first unit of the tail
+        constexpr int PC = 8;        // pending rows' units of a lane in flight at once
+#pragma unroll 1
+        for (int it = tid; it < nt * ntail; it += T) {
+            const int k = it / ntail, ut = ut0 + (it - k * ntail), ri = tlist[k];
+            double2 *px = reinterpret_cast<double2 *>(mat + (size_t)(b + NB * ri) * pitch) + ut;
+            double2 xv = *px;
+#pragma unroll 1
+            for (int p0 = 0; p0 < npend; p0 += PC) {
+                double2 pn_c[PC];
+#pragma unroll
+                for (int q = 0; q < PC; q++)
+                    if (p0 + q < npend) pn_c[q] = *(reinterpret_cast<const double2 *>(pend0 + (size_t)(p0 + q) * pitch) + ut);
+#pragma unroll
+                for (int q = 0; q < PC; q++) {
+                    const int p = p0 + q;
+                    if (p >= npend) break; // (uniform)
+                    const double coef = colv[p * rpw + ri];
+                    const bool piv = ri == pl[p];
+                    if (!(piv || fabs(coef) > 1e-16)) continue; // :31
+                    const double2 pn = pn_c[q];
+                    const bool f0 = (unsigned long long)__double_as_longlong(pn.x) != FLUSHED;
+                    const bool f1 = (unsigned long long)__double_as_longlong(pn.y) != FLUSHED;
+                    if (piv) {
+                        xv.x = f0 ? pn.x : 0.0;
+                        xv.y = f1 ? pn.y : 0.0;
+                    } else {
+                        const double px_ = coef * pn.x, py_ = coef * pn.y;
+                        const double nx = xv.x - px_, ny = xv.y - py_;
+                        xv.x = f0 ? nx : xv.x;
+                        xv.y = f1 ? ny : xv.y;
+                    }
+                    const int colxp = pc[p];
+                    if ((colxp >> 1) == ut) { // :25, :36 -- the one element of the row that the pivot column replaces
+                        const double patch = nqv[p * rpw + ri];
+                        if (colxp & 1)
+                            xv.y = patch;
+                        else
+                            xv.x = patch;
+                    }
+                }
+            }
+            *px = xv;
+        }
+    }
+    YSTAMP(16); // sweep: tail units
     __syncthreads(); // (the panel LDS may be reused by the caller)
+    YSTAMP(17); // sweep: last barrier
 }
 
 // ------------------------------------------------------------------------------------------

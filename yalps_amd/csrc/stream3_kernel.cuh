@@ -220,6 +220,9 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
         }
     };
     // every touched row streamed once, all pending eliminations in registers; afterwards nothing is pending
+#ifdef YALPS_STAMPS
+    unsigned long long st_acc[20] = {}, st_last = 0, st_t0 = 0, st_r0 = 0; // (diagnostic build; the sweep's own stages are summed inside panel_flush)
+#endif
     auto flush_pending = [&]() __attribute__((always_inline)) {
         if (npend == 0) return; // (uniform)
         int tl = tid;
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
             for (int j = 0; j < J; j++) row_st16<AUX_PLAIN>(rpk, lane_off + 16 * T * j, 0, ob[j]);
         }
         if constexpr (PANEL)
-            panel_flush<T, PU, 64, YALPS_PANEL_D, YALPS_PANEL_SETS, NT, (J == 16 && !CHECK) ? 4 : 8>(mat, pitch, b, NB, prow0, npend, colv0, nqv0, rpw, sh_pl, sh_pc, tlist, sh_nt, panel, rsrc_of); // (4: with 8 loads in flight hipcc spills three loop invariants of the pivot loop in that one instantiation)
+            panel_flush<T, PU, 64, YALPS_PANEL_D, YALPS_PANEL_SETS, NT, ((J == 16 || J == 8) && !CHECK) ? 4 : 8>(mat, pitch, b, NB, prow0, npend, colv0, nqv0, rpw, sh_pl, sh_pc, tlist, sh_nt, panel, rsrc_of YSTAMP_ARGS); // (4: with 8 loads in flight hipcc spills three loop invariants of the pivot loop in that one instantiation)
         else // (few rows per workgroup: the pending rows straight from my XCD's scratch, round 2's form -- the panels' barriers and LDS
              // fills cost more than they save there: 1025 x 16385, 4 rows per workgroup, 32 -> 38 us per pivot with panels)
             direct_flush<T, J, (J >= 8 ? 2 : 3), NT>(mat, pitch, b, NB, prow0, npend, colv0, nqv0, rpw, sh_pl, sh_pc, tlist, sh_nt, rsrc_of);
@@ -361,9 +364,11 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
             // can run it through the pending pivots in column slices (HP_SCAL doubles, write-through, drained before the record)
             if (tid < HP_SCAL) {
                 double v = 0.0;
-                if (tid == 0)
-                    v = rhsv[cg];
-                else if (tid == 1) {
+                if (tid == 0) {
+                    int off = (2 * depth + 1) * rpw; // (= rhsv - sm_dyn, worked out here in a scalar register: kept as a pointer across the pivot loop it was the one value hipcc spilled)
+                    asm volatile("" : "+s"(off));
+                    v = sm_dyn[off + cg];
+                } else if (tid == 1) {
                     int m = 0;
                     for (int p = 0; p < npend; p++) m |= (sh_pl[p] == cg ? 1 : 0) << p;
                     v = (double)m;
@@ -406,7 +411,6 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
     if (!stop) publish(candidate(phase));
 #ifdef YALPS_STAMPS
     // diagnostic build: stage sums over the launch's pivots (stages: tools/stream3_stages.py)
-    unsigned long long st_acc[20] = {}, st_last = 0, st_t0 = 0, st_r0 = 0;
     asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t0), "=s"(st_r0)::"memory");
     st_last = st_t0;
 #endif
