@@ -88,6 +88,9 @@ def check_register_budgets(lib=LIB, min_resident=15):
             bad.append("%s: vgpr_count %s agpr_count %s" % (name, md["vgpr_count"], md["agpr_count"]))
         if any(tag in name for tag in NO_SCRATCH) and int(md["private_segment_fixed_size"]) != 0:
             bad.append("%s: private_segment_fixed_size %s (scratch)" % (name, md["private_segment_fixed_size"]))
+    if bad and os.environ.get("YALPS_BUILD_ALLOW_SCRATCH") == "1":  # (experiments only: a same-box A/B of a form that does not fit yet)
+        print("register budget violated (YALPS_BUILD_ALLOW_SCRATCH=1: building anyway):\n  " + "\n  ".join(bad))
+        return ks
     if bad:
         raise RuntimeError("register budget violated (a spilling variant computes wrong rows):\n  " + "\n  ".join(bad))
     return ks

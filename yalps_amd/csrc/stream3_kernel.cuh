@@ -66,8 +66,8 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
     const int depth = d.delay_depth < 1 ? 1 : d.delay_depth > MAXD ? MAXD : d.delay_depth;
     double *colv0 = sm_dyn, *nqv0 = colv0 + (size_t)depth * rpw, *lav = nqv0 + (size_t)depth * rpw,
            *rhsv = lav + rpw; // (nqv: what replaces a row's pivot-column entry, :25 / :36 -- one division per row and pivot, by one lane)
-    int *tlist = reinterpret_cast<int *>(rhsv + rpw);
-    double *panel = rhsv + rpw + (rpw + 3) / 4 * 2; // (behind tlist, 16-byte aligned)
+    int *tlist = reinterpret_cast<int *>(rhsv + rpw), *tmask = tlist + (rpw + 3) / 4 * 4;
+    double *panel = rhsv + rpw + (rpw + 3) / 4 * 4; // (behind tlist and tmask, 16-byte aligned)
     const double flushed = __longlong_as_double((long long)FLUSHED);
     // The pending normalised pivot rows: one scratch PER XCD (d.pend: [8 XCDs][2 sets][depth][pitch]).  Every workgroup computes the
     // same rows from the same published bytes; the workgroups of one XCD store them to the same place (identical values;
@@ -232,13 +232,21 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
             for (int base = 0; base < my_rows; base += 64) {
                 const int i = base + tl;
                 bool t = false;
-                if (i < my_rows && b + i > 0) // (not the objective row: my replica of it IS that row with every pending pivot applied -- stored below)
-                    {
+                int msk = 0; // bit p: pending pivot p touches the row (:31, or its pivot row); bit 16 + p: the row is p's pivot row
+                if (i < my_rows && b + i > 0) { // (not the objective row: the replica of it IS that row with every pending pivot applied)
 #pragma unroll 4
-                    for (int p = 0; p < npend; p++) t = t | (i == sh_pl[p]) | (fabs(colv0[p * rpw + i]) > 1e-16); // (no short circuit: the LDS reads of four pending pivots in flight, not a chain of round trips)
+                    for (int p = 0; p < npend; p++) { // (no short circuit: the LDS reads of four pending pivots in flight, not a chain of round trips)
+                        const int pv = i == sh_pl[p] ? 1 : 0, tc = (pv | (fabs(colv0[p * rpw + i]) > 1e-16 ? 1 : 0));
+                        msk |= (tc << p) | (pv << (16 + p));
+                    }
+                    t = msk != 0;
                 }
                 const unsigned long long m = __ballot(t);
-                if (t) tlist[cnt + __popcll(m & ((1ull << tl) - 1ull))] = i;
+                if (t) {
+                    const int k = cnt + __popcll(m & ((1ull << tl) - 1ull));
+                    tlist[k] = i;
+                    tmask[k] = msk;
+                }
                 cnt += __popcll(m);
             }
             if (tl == 0) sh_nt = cnt;
@@ -262,7 +270,7 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
             for (int j = 0; j < J; j++) row_st16<AUX_PLAIN>(rpk, lane_off + 16 * T * j, 0, ob[j]);
         }
         if constexpr (PANEL)
-            panel_flush<T, PU, 64, YALPS_PANEL_D, YALPS_PANEL_SETS, NT, ((J == 16 || J == 8) && !CHECK) ? 4 : 8>(mat, pitch, b, NB, prow0, npend, colv0, nqv0, rpw, sh_pl, sh_pc, tlist, sh_nt, panel, rsrc_of YSTAMP_ARGS); // (4: with 8 loads in flight hipcc spills three loop invariants of the pivot loop in that one instantiation)
+            panel_flush<T, PU, 64, YALPS_PANEL_D, YALPS_PANEL_SETS, NT, ((J == 16 || J == 8) && !CHECK) ? 4 : 8>(mat, pitch, b, NB, prow0, npend, colv0, nqv0, rpw, sh_pl, sh_pc, tlist, tmask, sh_nt, panel, rsrc_of YSTAMP_ARGS); // (4: with 8 loads in flight hipcc spills three loop invariants of the pivot loop in that one instantiation)
         else // (few rows per workgroup: the pending rows straight from my XCD's scratch, round 2's form -- the panels' barriers and LDS
              // fills cost more than they save there: 1025 x 16385, 4 rows per workgroup, 32 -> 38 us per pivot with panels)
             direct_flush<T, J, (J >= 8 ? 2 : 3), NT>(mat, pitch, b, NB, prow0, npend, colv0, nqv0, rpw, sh_pl, sh_pc, tlist, sh_nt, rsrc_of);

@@ -827,7 +827,7 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
                                              : std::min(8, sJ >= 8 ? (rows_per_block >= 8 ? 8 : 6) : std::max(4, (rows_per_block + 1) / 3));
             int depth3 = std::min(STREAM3_MAXD, std::max(2, env_int("YALPS_HIP_DELAY_DEPTH", depth_default)));
             auto lds3_of = [&](int dep) {
-                return sizeof(double) * (2 * (size_t)dep + 2) * (size_t)rows_per_block + sizeof(int32_t) * (((size_t)rows_per_block + 3) / 4 * 4) +
+                return sizeof(double) * (2 * (size_t)dep + 2) * (size_t)rows_per_block + 2 * sizeof(int32_t) * (((size_t)rows_per_block + 3) / 4 * 4) +
                        (panel3 ? sizeof(double) * (size_t)dep * 2 * STREAM3_PANEL_UNITS : 0);
             };
             while (depth3 > 2 && lds3_of(depth3) > 150 * 1024) depth3--;
@@ -1963,7 +1963,7 @@ int32_t yalps_tableau_set_shard(yalps_tableau *t, int32_t rank, int32_t nranks, 
             const int depth_default = panel ? DSHARD_DEFAULT_DEPTH_PANEL : rows_per_block >= 12 ? 16 : DSHARD_DEFAULT_DEPTH;
             int depth = std::min(DSHARD_MAXD, std::max(2, env_int("YALPS_HIP_DELAY_DEPTH", depth_default)));
             auto lds_of = [&](int dep) {
-                return sizeof(double) * (2 * (size_t)dep + 2) * (size_t)rows_per_block + sizeof(int32_t) * (((size_t)rows_per_block + 3) / 4 * 4) +
+                return sizeof(double) * (2 * (size_t)dep + 2) * (size_t)rows_per_block + 2 * sizeof(int32_t) * (((size_t)rows_per_block + 3) / 4 * 4) +
                        (panel ? sizeof(double) * (size_t)dep * 2 * DSHARD_PANEL_UNITS : 0);
             };
             while (depth > 2 && lds_of(depth) > 150 * 1024) depth--;
