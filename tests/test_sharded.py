@@ -109,7 +109,7 @@ DELAYED = [
     ("hip", 2, 2300, 4200, 6, 150, False, {}, "dshard_kernel<512,6>,delay_depth:8"),
     ("hip-native", 3, 3300, 4200, 5, 131, True, {}, "dshard_kernel<512,6>,delay_depth:8"),
     # round 3: up to 16 pending pivots (the sweep stages them in LDS, panel_flush.cuh); budgets between two sweeps
-    # (the sweep through LDS panels, forced onto small shards -- by default it is taken from 24 rows per workgroup on --, and the
+    # (the sweep through LDS panels, forced onto small shards -- by default it is taken from 12 rows per workgroup on --, and the
     # pending rows straight from L2 at depths beyond 8)
     ("hip", 2, 2300, 4200, 6, 150, False, {"YALPS_HIP_DELAY_DEPTH": "16", "YALPS_HIP_SHARD_PANEL": "1"}, "dshard_kernel<512,6,panel>,delay_depth:16"),
     ("hip-native", 3, 3300, 4200, 5, 131, True, {"YALPS_HIP_DELAY_DEPTH": "12", "YALPS_HIP_SHARD_PANEL": "1"}, "dshard_kernel<512,6,panel>,delay_depth:12"),

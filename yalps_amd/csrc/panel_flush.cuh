@@ -119,7 +119,7 @@ __device__ __forceinline__ void panel_flush(double *mat, int pitch, int b, int N
             for (int d = 0; d < D; d++) {
                 const int k = k0 + d * RS + sub;
                 ri[d] = k < nt ? tlist[k] : -1; // my row slot of each row in flight (-1: none)
-                rm[d] = k < nt ? tmask[k] : 0;  // which pending pivots touch it / have it as their pivot row
+                rm[d] = k < nt ? tmask[k] : 0xffff; // which pending pivots touch it / have it as their pivot row (no row: whatever suits the others -- its registers are never stored)
                 const __amdgpu_buffer_rsrc_t rs = rsrc_of(mat + (size_t)(b + NB * (ri[d] < 0 ? r_any : ri[d])) * pitch);
 #pragma unroll
                 for (int u = 0; u < U; u++) x[d][u] = row_ld16<AUX>(rs, 16 * (u0 + lane + u * LU), 0);
@@ -341,7 +341,7 @@ __device__ __forceinline__ void panel_flush(double *mat, int pitch, int b, int N
 // 64 rows per workgroup).  The host picks by rows per workgroup (yalps_hip.hip, DSHARD_PANEL_MIN_ROWS).
 // Lane `tid` holds units tid, tid + T, ... of a row; lane_off = 16 * tid.
 // ------------------------------------------------------------------------------------------
-template <int T, int J, int RB, bool NT, typename RsrcOf>
+template <int T, int J, int RB, bool NT, bool PF = true, typename RsrcOf>
 __device__ __forceinline__ void direct_flush(double *mat, int pitch, int b, int NB, const double *pend0, int npend, const double *colv,
                                              const double *nqv, int rpw, const int *pl, const int *pc, const int *tlist, int nt, RsrcOf rsrc_of) {
     constexpr int JH = J > 8 ? 8 : J, JA = JH; // (RB (half-)rows of JH units per lane in registers)
@@ -365,9 +365,14 @@ __device__ __forceinline__ void direct_flush(double *mat, int pitch, int b, int 
                 }
             }
             const int cnt = nt - k;
-#pragma unroll 1
-            for (int p = 0; p < npend; p++) {
+            // (the L2 reads of pending row p + 1 are in flight while row p is applied: a read followed by the arithmetic on it was one
+            // L2 round trip per pending pivot and batch that nothing covered -- the waves of a workgroup walk the pending pivots in step)
+            auto rd_pend = [&](int p, double2 (&pn)[JA]) __attribute__((always_inline)) {
                 const __amdgpu_buffer_rsrc_t rsp = rsrc_of(pend0 + (size_t)p * pitch);
+#pragma unroll
+                for (int j = 0; j < JA; j++) pn[j] = row_ld16<AUX_PLAIN>(rsp, lane_off + 16 * T * (u0 + j), 0);
+            };
+            auto apply_pend = [&](int p, const double2 (&pn)[JA]) __attribute__((always_inline)) {
                 const int colxp = pc[p], lslotp = pl[p];
                 // the one element of a row that the pivot column replaces (:25, :36): unit `up` of lane `lp`
                 const int up = (colxp >> 1) / T;
@@ -381,9 +386,6 @@ __device__ __forceinline__ void direct_flush(double *mat, int pitch, int b, int 
                     pivu[u] = ri[u] == lslotp;
                     actu[u] = u < cnt && (pivu[u] || fabs(coefu[u]) > 1e-16); // :31
                 }
-                double2 pn[JA];
-#pragma unroll
-                for (int j = 0; j < JA; j++) pn[j] = row_ld16<AUX_PLAIN>(rsp, lane_off + 16 * T * (u0 + j), 0);
                 bool fl = false; // (per wave: nothing of these units was flushed -> the select-free path)
 #pragma unroll
                 for (int j = 0; j < JA; j++)
@@ -421,6 +423,29 @@ __device__ __forceinline__ void direct_flush(double *mat, int pitch, int b, int 
                             }
                         }
                     }
+                }
+            };
+            if constexpr (PF) {
+                double2 pna[JA], pnb[JA];
+                rd_pend(0, pna);
+#pragma unroll 1
+                for (int p = 0; p < npend; p += 2) {
+                    const int p1 = p + 1 < npend ? p + 1 : p, p2 = p + 2 < npend ? p + 2 : p; // (past the end: a row read again, nobody uses it)
+                    rd_pend(p1, pnb);
+                    __builtin_amdgcn_sched_barrier(0);
+                    apply_pend(p, pna);
+                    __builtin_amdgcn_sched_barrier(0);
+                    rd_pend(p2, pna);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (p + 1 < npend) apply_pend(p + 1, pnb); // (uniform)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll 1
+                for (int p = 0; p < npend; p++) {
+                    double2 pn[JA];
+                    rd_pend(p, pn);
+                    apply_pend(p, pn);
                 }
             }
 #pragma unroll

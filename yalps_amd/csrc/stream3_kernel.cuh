@@ -255,7 +255,7 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
         // (panel_flush.cuh: the pending rows staged in LDS one 1024-column panel at a time, a wave per row, eight units per lane, two rows in flight per wave)
         // Wide rows: the objective replica's 4 J registers per lane are parked in global memory for the duration of the sweep (2 x
         // 8 w bytes per workgroup and sweep against 16 w bytes per ROW): with them live, the 16-unit forms spill in the sweep.
-        constexpr bool PARK = J > 8 || (PANEL && J >= 6);
+        constexpr bool PARK = J >= 6;
         // The objective row is not swept: workgroup 0 stores its replica -- the same arithmetic, pivot by pivot (:27-38 for row 0) -- over it.
         // (With it the first workgroup had one row more than the others wherever the row count is 2^k + 1 -- every BASELINE
         // configuration: a fifth trip of 8 waves x 2 rows per panel for ONE row at 16385^2, a second one at 4097^2, everybody waiting.)
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
             panel_flush<T, PU, 64, YALPS_PANEL_D, YALPS_PANEL_SETS, NT, ((J == 16 || J == 8) && !CHECK) ? 4 : 8>(mat, pitch, b, NB, prow0, npend, colv0, nqv0, rpw, sh_pl, sh_pc, tlist, tmask, sh_nt, panel, rsrc_of YSTAMP_ARGS); // (4: with 8 loads in flight hipcc spills three loop invariants of the pivot loop in that one instantiation)
         else // (few rows per workgroup: the pending rows straight from my XCD's scratch, round 2's form -- the panels' barriers and LDS
              // fills cost more than they save there: 1025 x 16385, 4 rows per workgroup, 32 -> 38 us per pivot with panels)
-            direct_flush<T, J, (J >= 8 ? 2 : 3), NT>(mat, pitch, b, NB, prow0, npend, colv0, nqv0, rpw, sh_pl, sh_pc, tlist, sh_nt, rsrc_of);
+            direct_flush<T, J, (J >= 8 ? 2 : 3), NT, !(J == 16 && CHECK)>(mat, pitch, b, NB, prow0, npend, colv0, nqv0, rpw, sh_pl, sh_pc, tlist, sh_nt, rsrc_of);
         if constexpr (PARK) { // (same lane, same addresses: the stores above are ordered in front of these loads)
             const __amdgpu_buffer_rsrc_t rpk = rsrc_of(d.ob_park + (size_t)b * pitch);
 #pragma unroll

@@ -148,7 +148,7 @@ const std::vector<RVariant> kDshard = variants_of({yalps_dshard_table()}); // (l
 constexpr size_t SWEEP_BEYOND_CACHE = 200u << 20; // tableau bytes from which row traffic goes non-temporal (Infinity Cache: 256 MiB)
 constexpr int STREAM3_PANEL_MIN_ROWS = 12; // rows per workgroup from which stream3_kernel's sweep goes through LDS panels (panel_flush.cuh)
 constexpr int STREAM3_DEFAULT_DEPTH_WIDE = 16; // pending pivots of stream3_kernel for rows of 4098+ columns with 8+ rows per workgroup (YALPS_HIP_DELAY_DEPTH)
-constexpr int DSHARD_PANEL_MIN_ROWS = 24;      // rows per workgroup from which a row shard's sweep goes through LDS panels (panel_flush.cuh)
+constexpr int DSHARD_PANEL_MIN_ROWS = 12;      // rows per workgroup from which a row shard's sweep goes through LDS panels (panel_flush.cuh)
 constexpr int DSHARD_DEFAULT_DEPTH_PANEL = 16; // ... and its pending pivots then
 constexpr int DSHARD_DEFAULT_DEPTH = 8; // pending pivots of a row shard (YALPS_HIP_DELAY_DEPTH, at most DSHARD_MAXD = 16)
 constexpr int RESIDENT_CHUNK = 4096; // pivots per launch of the resident kernel (bounds its run time)
@@ -824,7 +824,7 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
             // 6001^2 28.1, 8193^2 37.5, 16385^2 87.8 -- round 2: 33.4, 45.5, 141).
             const bool panel3 = env_int("YALPS_HIP_STREAM3_PANEL", rows_per_block >= STREAM3_PANEL_MIN_ROWS ? 1 : 0) != 0;
             const int depth_default = panel3 ? STREAM3_DEFAULT_DEPTH_WIDE
-                                             : std::min(8, sJ >= 8 ? (rows_per_block >= 8 ? 8 : 6) : std::max(4, (rows_per_block + 1) / 3));
+                                             : sJ >= 8 ? (rows_per_block >= 8 ? 12 : 6) : std::min(8, std::max(4, (rows_per_block + 1) / 3)); // (2049 x 16385 from L2 at depth 8 / 12 / 16: 35.8 / 34.8 / 34.9 us per pivot)
             int depth3 = std::min(STREAM3_MAXD, std::max(2, env_int("YALPS_HIP_DELAY_DEPTH", depth_default)));
             auto lds3_of = [&](int dep) {
                 return sizeof(double) * (2 * (size_t)dep + 2) * (size_t)rows_per_block + 2 * sizeof(int32_t) * (((size_t)rows_per_block + 3) / 4 * 4) +
@@ -1960,7 +1960,10 @@ int32_t yalps_tableau_set_shard(yalps_tableau *t, int32_t rank, int32_t nranks, 
             const bool panel = env_int("YALPS_HIP_SHARD_PANEL", rows_per_block >= DSHARD_PANEL_MIN_ROWS ? 1 : 0) != 0;
             // (measured, one rank, 16385 columns, us per pivot: 2049 rows -- 8 per workgroup -- straight from L2 48 at depth 8, panels 52;
             // 4097 rows 63 / 59.5 at depth 8 / 16 from L2, panels 60; 8193 rows 91 from L2, panels 86 / 74 at depth 8 / 16; 16385 rows panels 102)
-            const int depth_default = panel ? DSHARD_DEFAULT_DEPTH_PANEL : rows_per_block >= 12 ? 16 : DSHARD_DEFAULT_DEPTH;
+            // (round 3, after the panel sweep lost its chains of round trips -- one rank, 16385 columns, us per pivot from L2 / through panels at
+            // depth 8, 12, 16: 2049 rows (8 per workgroup) 45.3 43.8 43.3 / 48.3 46.9 46.3; 4097 rows (16) 60.5 57.7 56.6 / 56.0 51.0 49.1;
+            // 6001 rows (24) 74.0 70.3 74.5 / 70.7 61.0 58.5)
+            const int depth_default = panel ? DSHARD_DEFAULT_DEPTH_PANEL : rows_per_block >= 8 ? 16 : DSHARD_DEFAULT_DEPTH;
             int depth = std::min(DSHARD_MAXD, std::max(2, env_int("YALPS_HIP_DELAY_DEPTH", depth_default)));
             auto lds_of = [&](int dep) {
                 return sizeof(double) * (2 * (size_t)dep + 2) * (size_t)rows_per_block + 2 * sizeof(int32_t) * (((size_t)rows_per_block + 3) / 4 * 4) +
