@@ -193,7 +193,7 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
         __syncthreads();
         // (panel_flush.cuh: the pending rows staged in LDS one column panel at a time, a wave per row, eight units per lane, two rows in flight per wave)
         if constexpr (PANEL)
-            panel_flush<T, PU, 64, YALPS_PANEL_D, YALPS_PANEL_SETS, NT>(mat, pitch, b, NB, prow0, npend, colv0, nqv0, rpw, sh_pl, sh_pc, tlist, tmask, sh_nt, panel, rsrc_of YSTAMP_ARGS);
+            panel_flush<T, PU, 64, YALPS_PANEL_D, YALPS_PANEL_SETS, NT, 8, (J < 16)>(mat, pitch, b, NB, prow0, npend, colv0, nqv0, rpw, sh_pl, sh_pc, tlist, tmask, sh_nt, panel, rsrc_of YSTAMP_ARGS);
         else // (few rows per workgroup: the pending rows straight from L2, round 2's form)
             direct_flush<T, J, (J > 8 ? 4 : 3), NT>(mat, pitch, b, NB, prow0, npend, colv0, nqv0, rpw, sh_pl, sh_pc, tlist, sh_nt, rsrc_of);
         npend = 0;

@@ -30,7 +30,7 @@
 // tlist[0 .. nt) = my row slots touched by at least one pending pivot, tmask[k] = for row tlist[k], bit p: pending pivot p touches it
 // (:31 or its pivot row), bit 16 + p: it is p's pivot row.  Rows and pending rows are addressed through buffer
 // descriptors of one row (rsrc_of): units past the pitch read as 0.0 and their stores are dropped.
-template <int T, int PU, int LU, int D, int SETS, bool NT, int CH = 8, typename RsrcOf>
+template <int T, int PU, int LU, int D, int SETS, bool NT, int CH = 8, bool DYN = true, typename RsrcOf>
 __device__ __forceinline__ void panel_flush(double *mat, int pitch, int b, int NB, const double *pend0, int npend, const double *colv,
                                             const double *nqv, int rpw, const int *pl, const int *pc, const int *tlist, const int *tmask, int nt, double *panel,
                                             RsrcOf rsrc_of YSTAMP_PARAMS) {
@@ -44,6 +44,7 @@ __device__ __forceinline__ void panel_flush(double *mat, int pitch, int b, int N
     constexpr int U = PU / LU; // units per lane and row
     constexpr int AUX = NT ? AUX_NT : AUX_PLAIN;
     __shared__ unsigned sh_slow[T / 64]; // per wave of the fill: pending rows with a flushed entry among the units it copied
+    __shared__ int sh_next;              // the next pair of rows of this panel nobody has taken yet (the waves take them as they get free)
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid)); // (opaque: the lane's LDS and row offsets are recomputed here, not hoisted out of the caller's pivot loop and kept -- or spilled -- there)
     const int sub = tid / LU, lane = tid % LU;
@@ -93,6 +94,7 @@ __device__ __forceinline__ void panel_flush(double *mat, int pitch, int b, int N
                 }
             }
             if ((tid & 63) == 0) sh_slow[tid >> 6] = slow;
+            if (tid == 0) sh_next = 0;
         }
         YSTAMP(11); // sweep: panel fill
         __syncthreads();
@@ -117,7 +119,7 @@ __device__ __forceinline__ void panel_flush(double *mat, int pitch, int b, int N
         auto load_set = [&](int k0, double2 (&x)[D][U], int (&ri)[D], int (&rm)[D]) __attribute__((always_inline)) {
 #pragma unroll
             for (int d = 0; d < D; d++) {
-                const int k = k0 + d * RS + sub;
+                const int k = DYN ? k0 + d : k0 + d * RS + sub;
                 ri[d] = k < nt ? tlist[k] : -1; // my row slot of each row in flight (-1: none)
                 rm[d] = k < nt ? tmask[k] : 0xffff; // which pending pivots touch it / have it as their pivot row (no row: whatever suits the others -- its registers are never stored)
                 const __amdgpu_buffer_rsrc_t rs = rsrc_of(mat + (size_t)(b + NB * (ri[d] < 0 ? r_any : ri[d])) * pitch);
@@ -260,9 +262,19 @@ __device__ __forceinline__ void panel_flush(double *mat, int pitch, int b, int N
                 for (int u = 0; u < U; u++) row_st16<AUX>(rs, 16 * (u0 + lane + u * LU), 0, x[d][u]);
             }
         };
-        static_assert(SETS == 1 || SETS == 2, "register sets of D rows in flight per wave");
+        // The waves of a workgroup TAKE their rows, D at a time, from a counter in LDS as they get free: with a fixed share a wave whose
+        // loads came back late kept everybody waiting at the next panel's barrier (stage stamps at 16385^2: 15 % of a sweep).
+        static_assert(SETS == 1 && LU == 64, "a wave takes D rows per trip");
+        // (DYN = false: the fixed share -- same box, alternating runs, us per pivot taken / fixed: 6001^2 25.7 / 26.5, 8193^2 32.8 / 32.95,
+        // 4097^2 18.7 / 18.6, but 16385^2 79.7 / 76.8: the callers keep the fixed share for rows of 16 units per lane)
 #pragma unroll 1
-        for (int k0 = 0; k0 < nt; k0 += SETS * RS * D) {
+        for (int kf = 0;; kf += RS * D) {
+            int k0 = kf;
+            if constexpr (DYN) {
+                if ((tid & 63) == 0) k0 = __hip_atomic_fetch_add(&sh_next, D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                k0 = __builtin_amdgcn_readlane(k0, 0);
+            }
+            if (k0 >= nt) break; // (uniform)
             double2 xa[D][U], xb[SETS == 2 ? D : 1][U];
             int ria[D], rib[SETS == 2 ? D : 1], rma[D], rmb[SETS == 2 ? D : 1];
             YSTAMP(12); // sweep: barrier behind the fill, flags / between trips

@@ -270,7 +270,7 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
             for (int j = 0; j < J; j++) row_st16<AUX_PLAIN>(rpk, lane_off + 16 * T * j, 0, ob[j]);
         }
         if constexpr (PANEL)
-            panel_flush<T, PU, 64, YALPS_PANEL_D, YALPS_PANEL_SETS, NT, ((J == 16 || J == 8) && !CHECK) ? 4 : 8>(mat, pitch, b, NB, prow0, npend, colv0, nqv0, rpw, sh_pl, sh_pc, tlist, tmask, sh_nt, panel, rsrc_of YSTAMP_ARGS); // (4: with 8 loads in flight hipcc spills three loop invariants of the pivot loop in that one instantiation)
+            panel_flush<T, PU, 64, YALPS_PANEL_D, YALPS_PANEL_SETS, NT, 4, (J < 16 || CHECK)>(mat, pitch, b, NB, prow0, npend, colv0, nqv0, rpw, sh_pl, sh_pc, tlist, tmask, sh_nt, panel, rsrc_of YSTAMP_ARGS); // (4 loads of the fill in flight: with 8 hipcc spills loop invariants of the pivot loop in some instantiations; J < 16: the waves take their rows from a counter)
         else // (few rows per workgroup: the pending rows straight from my XCD's scratch, round 2's form -- the panels' barriers and LDS
              // fills cost more than they save there: 1025 x 16385, 4 rows per workgroup, 32 -> 38 us per pivot with panels)
             direct_flush<T, J, (J >= 8 ? 2 : 3), NT, !(J == 16 && CHECK)>(mat, pitch, b, NB, prow0, npend, colv0, nqv0, rpw, sh_pl, sh_pc, tlist, sh_nt, rsrc_of);
@@ -380,10 +380,12 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
                     int m = 0;
                     for (int p = 0; p < npend; p++) m |= (sh_pl[p] == cg ? 1 : 0) << p;
                     v = (double)m;
-                } else if (tid >= 8 && tid < 8 + MAXD) {
-                    if (tid - 8 < npend) v = colv0[(tid - 8) * rpw + cg];
-                } else if (tid >= 8 + MAXD && tid < 8 + 2 * MAXD) {
-                    if (tid - 8 - MAXD < npend) v = nqv0[(tid - 8 - MAXD) * rpw + cg];
+                } else if (tid >= 8 && tid < 8 + 2 * MAXD) { // (colv0 / nqv0 = sm_dyn + 0 / + depth * rpw: the offset worked out here in a scalar register, as above)
+                    const int q = tid - 8, pq = q < MAXD ? q : q - MAXD;
+                    int off = q < MAXD ? 0 : depth * rpw;
+                    int base0 = 0;
+                    asm volatile("" : "+s"(base0));
+                    if (pq < npend) v = sm_dyn[base0 + off + pq * rpw + cg];
                 }
                 st_sc1(d.hp_scal + ((size_t)par * NB + b) * HP_SCAL + tid, v);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
