@@ -66,6 +66,12 @@ constexpr int HP_SCAL = 8 + 2 * 16; // doubles a workgroup publishes with its ca
                                     // RHS entry, [1] bit p: it was pending pivot p's pivot row, [8 + p] its entry of p's column as it was, [8 + 16 + p] what replaces it
 constexpr int STREAM3_MAXD = 16;         // pending pivots stream3_kernel can hold (the depth in use is Desc::delay_depth)
 constexpr int STREAM3_PANEL_UNITS = 512; // 16-byte units of a row per LDS panel of its sweep (panel_flush.cuh): 1024 columns
+// (Tried for rows of 16 units per lane: panels of 384 units and up to 22 pending pivots -- what the LDS of a CU holds that way.  Same
+// box, whole solves at 16385^2: 384 units / 16 pending 80.3 us per pivot, / 20 76.3, / 22 74.6, against 76.8 with 512 units / 16; at
+// 4097 x 16385 and 3001 x 16385 every 384-unit form lost 1-2 us.  A pending pivot more costs a sweep what its arithmetic costs --
+// 29 us at 16385^2 --: the sweep is the SUM of the rows' memory time and the arithmetic, not the larger of the two.)
+__host__ __device__ constexpr int stream3_panel_units(int) { return STREAM3_PANEL_UNITS; }
+constexpr int STREAM3_DEPTH_J16 = 16;    // pending pivots of the 16-unit form by default
 constexpr int DSHARD_MAXD = 16;          // pending pivots a row shard can hold (dshard_kernel.cuh); the depth in use is Desc::delay_depth
 constexpr int DSHARD_PANEL_UNITS = 512;  // 16-byte units of a row per LDS panel of its sweep (panel_flush.cuh): 1024 columns
 

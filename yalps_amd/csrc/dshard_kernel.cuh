@@ -67,8 +67,8 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
     const int my_rows = b < h ? (h - 1 - b) / NB + 1 : 0;
     const int depth = d.delay_depth < 1 ? 1 : d.delay_depth > MAXD ? MAXD : d.delay_depth;
     double *colv0 = sm_dyn, *nqv0 = colv0 + (size_t)depth * rpw, *lav = nqv0 + (size_t)depth * rpw, *rhsv = lav + rpw;
-    int *tlist = reinterpret_cast<int *>(rhsv + rpw), *tmask = tlist + (rpw + 3) / 4 * 4;
-    double *panel = rhsv + rpw + (rpw + 3) / 4 * 4; // (behind tlist and tmask, 16-byte aligned: rpw ints each, rounded up to a multiple of four)
+    int *tlist = reinterpret_cast<int *>(rhsv + rpw), *tmask = tlist + (rpw + 3) / 4 * 4, *tpiv = tmask + (rpw + 3) / 4 * 4;
+    double *panel = rhsv + rpw + (rpw + 3) / 4 * 6; // (behind tlist, tmask and tpiv, 16-byte aligned: rpw ints each, rounded up to a multiple of four)
     const double flushed = __longlong_as_double((long long)FLUSHED);
     double *const prow0 = d.dpend;
     int npend = Din->npend;
@@ -171,12 +171,13 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
             for (int base = 0; base < my_rows; base += 64) {
                 const int i = base + tid;
                 bool t = false;
-                int msk = 0; // bit p: pending pivot p touches the row (:31, or its pivot row); bit 16 + p: the row is p's pivot row
+                int msk = 0, pvm = 0; // bit p of msk: pending pivot p touches the row (:31, or its pivot row); of pvm: the row is p's pivot row
                 if (i < my_rows && b + i > 0) { // (not the objective row: the replica of it IS that row with every pending pivot applied)
 #pragma unroll 4
                     for (int p = 0; p < npend; p++) { // (no short circuit: the LDS reads of four pending pivots in flight, not a chain of round trips)
                         const int pv = i == sh_pl[p] ? 1 : 0, tc = (pv | (fabs(colv0[p * rpw + i]) > 1e-16 ? 1 : 0));
-                        msk |= (tc << p) | (pv << (16 + p));
+                        msk |= tc << p;
+                        pvm |= pv << p;
                     }
                     t = msk != 0;
                 }
@@ -185,6 +186,7 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
                     const int k = cnt + __popcll(m & ((1ull << tid) - 1ull));
                     tlist[k] = i;
                     tmask[k] = msk;
+                    tpiv[k] = pvm;
                 }
                 cnt += __popcll(m);
             }
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
         __syncthreads();
         // (panel_flush.cuh: the pending rows staged in LDS one column panel at a time, a wave per row, eight units per lane, two rows in flight per wave)
         if constexpr (PANEL)
-            panel_flush<T, PU, 64, YALPS_PANEL_D, YALPS_PANEL_SETS, NT, 8, (J < 16)>(mat, pitch, b, NB, prow0, npend, colv0, nqv0, rpw, sh_pl, sh_pc, tlist, tmask, sh_nt, panel, rsrc_of YSTAMP_ARGS);
+            panel_flush<T, PU, 64, YALPS_PANEL_D, YALPS_PANEL_SETS, NT, 8, (J < 16)>(mat, pitch, b, NB, prow0, npend, colv0, nqv0, rpw, sh_pl, sh_pc, tlist, tmask, tpiv, sh_nt, panel, rsrc_of YSTAMP_ARGS);
         else // (few rows per workgroup: the pending rows straight from L2, round 2's form)
             direct_flush<T, J, (J > 8 ? 4 : 3), NT>(mat, pitch, b, NB, prow0, npend, colv0, nqv0, rpw, sh_pl, sh_pc, tlist, sh_nt, rsrc_of);
         npend = 0;

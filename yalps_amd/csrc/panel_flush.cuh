@@ -28,11 +28,11 @@
 // `panel` is LDS for MAXD x 2 PU doubles; colv / nqv are [npend][rpw] LDS arrays of my rows' pivot-column entries as they
 // were and what replaces them; pl[p] = my slot of pending pivot p's pivot row or -1, pc[p] = its pivot column (mat index);
 // tlist[0 .. nt) = my row slots touched by at least one pending pivot, tmask[k] = for row tlist[k], bit p: pending pivot p touches it
-// (:31 or its pivot row), bit 16 + p: it is p's pivot row.  Rows and pending rows are addressed through buffer
+// (:31 or its pivot row); tpiv[k], bit p: it is p's pivot row.  Rows and pending rows are addressed through buffer
 // descriptors of one row (rsrc_of): units past the pitch read as 0.0 and their stores are dropped.
 template <int T, int PU, int LU, int D, int SETS, bool NT, int CH = 8, bool DYN = true, typename RsrcOf>
 __device__ __forceinline__ void panel_flush(double *mat, int pitch, int b, int NB, const double *pend0, int npend, const double *colv,
-                                            const double *nqv, int rpw, const int *pl, const int *pc, const int *tlist, const int *tmask, int nt, double *panel,
+                                            const double *nqv, int rpw, const int *pl, const int *pc, const int *tlist, const int *tmask, const int *tpiv, int nt, double *panel,
                                             RsrcOf rsrc_of YSTAMP_PARAMS) {
     // LU lanes across a row segment of PU units: U = PU / LU units per lane and row, RS = T / LU rows side by side.  One WAVE per
     // row (LU = 64, eight units per lane) is what keeps the sweep off the vector ALU: what a pending pivot costs a row apart
@@ -116,18 +116,19 @@ __device__ __forceinline__ void panel_flush(double *mat, int pitch, int b, int N
         // reuse the registers the previous batch's stores read, hipcc waits for those stores to COMPLETE first, and a wave had
         // one batch of D x 16 bytes per lane per HBM write + read latency in flight: 2.7 TB/s at 16385^2.)
         const int r_any = tlist[0]; // (a valid slot for the unconditional reads of the rows that are not there)
-        auto load_set = [&](int k0, double2 (&x)[D][U], int (&ri)[D], int (&rm)[D]) __attribute__((always_inline)) {
+        auto load_set = [&](int k0, double2 (&x)[D][U], int (&ri)[D], int (&rm)[D], int (&rp)[D]) __attribute__((always_inline)) {
 #pragma unroll
             for (int d = 0; d < D; d++) {
                 const int k = DYN ? k0 + d : k0 + d * RS + sub;
                 ri[d] = k < nt ? tlist[k] : -1; // my row slot of each row in flight (-1: none)
-                rm[d] = k < nt ? tmask[k] : 0xffff; // which pending pivots touch it / have it as their pivot row (no row: whatever suits the others -- its registers are never stored)
+                rm[d] = k < nt ? tmask[k] : -1;     // which pending pivots touch it (no row: whatever suits the others -- its registers are never stored) ...
+                rp[d] = k < nt ? tpiv[k] : 0;       // ... and which have it as their pivot row
                 const __amdgpu_buffer_rsrc_t rs = rsrc_of(mat + (size_t)(b + NB * (ri[d] < 0 ? r_any : ri[d])) * pitch);
 #pragma unroll
                 for (int u = 0; u < U; u++) x[d][u] = row_ld16<AUX>(rs, 16 * (u0 + lane + u * LU), 0);
             }
         };
-        auto apply_set = [&](double2 (&x)[D][U], const int (&ri)[D], const int (&rm)[D]) __attribute__((always_inline)) {
+        auto apply_set = [&](double2 (&x)[D][U], const int (&ri)[D], const int (&rm)[D], const int (&rp)[D]) __attribute__((always_inline)) {
             // The LDS reads of a pending pivot run ONE HALF AHEAD of the arithmetic: while the units [0, UH) of pending pivot p are
             // worked on, its units [UH, U) are on their way; while those are worked on, pivot p + 1's first half and its scalars
             // (my rows' coefficients, its column, its pivot-row slot).  All waves of a workgroup walk the pending pivots in step
@@ -202,8 +203,7 @@ __device__ __forceinline__ void panel_flush(double *mat, int pitch, int b, int N
             unsigned plain = fastmask & ~colmask;
 #pragma unroll
             for (int d = 0; d < D; d++) { // (the rows' masks were made with the list of touched rows, once per sweep)
-                const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane(rm[d]);
-                plain &= (m & 0xffffu) & ~(m >> 16);
+                plain &= (unsigned)__builtin_amdgcn_readfirstlane(rm[d]) & ~(unsigned)__builtin_amdgcn_readfirstlane(rp[d]);
             }
             auto straight = [&](const double (&cf_c)[D], int ub, const double2 (&pn_c)[UH]) __attribute__((always_inline)) {
 #pragma unroll
@@ -276,20 +276,20 @@ __device__ __forceinline__ void panel_flush(double *mat, int pitch, int b, int N
             }
             if (k0 >= nt) break; // (uniform)
             double2 xa[D][U], xb[SETS == 2 ? D : 1][U];
-            int ria[D], rib[SETS == 2 ? D : 1], rma[D], rmb[SETS == 2 ? D : 1];
+            int ria[D], rib[SETS == 2 ? D : 1], rma[D], rmb[SETS == 2 ? D : 1], rpa[D], rpb[SETS == 2 ? D : 1];
             YSTAMP(12); // sweep: barrier behind the fill, flags / between trips
-            load_set(k0, xa, ria, rma);
-            if constexpr (SETS == 2) load_set(k0 + RS * D, xb, rib, rmb);
+            load_set(k0, xa, ria, rma, rpa);
+            if constexpr (SETS == 2) load_set(k0 + RS * D, xb, rib, rmb, rpb);
 #ifdef YALPS_STAMPS
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
             YSTAMP(13); // sweep: my rows' loads (diagnostic build waits for them here)
-            apply_set(xa, ria, rma);
+            apply_set(xa, ria, rma, rpa);
             YSTAMP(14); // sweep: the pending pivots applied in registers
             store_set(xa, ria);
             YSTAMP(15); // sweep: stores issued
             if constexpr (SETS == 2) {
-                apply_set(xb, rib, rmb);
+                apply_set(xb, rib, rmb, rpb);
                 store_set(xb, rib);
             }
         }

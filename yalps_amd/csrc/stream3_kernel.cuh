@@ -28,7 +28,7 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
     __shared__ double sh_hs[HP_SCAL];     // the winner's row's scalars as its owner published them (layout: publish())
     __shared__ int sh_hk[2];              // my index among the workgroups of my XCD, and their number
     constexpr int MAXD = STREAM3_MAXD;
-    constexpr int PU = STREAM3_PANEL_UNITS; // 16-byte units of a row per LDS panel of the sweep (panel_flush.cuh)
+    constexpr int PU = stream3_panel_units(J); // 16-byte units of a row per LDS panel of the sweep (panel_flush.cuh)
     // TWO: the exchange in two steps -- every workgroup publishes its candidate's KEY only; the workgroup that owns the winner
     // then publishes that one row (pending pivots applied) behind a second record.  One more hand-off on the pivot's chain,
     // but 1 row instead of 256 goes through the pending pivots and the L2s per pivot (at 16 units per lane that was 335 MB of
@@ -66,8 +66,8 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
     const int depth = d.delay_depth < 1 ? 1 : d.delay_depth > MAXD ? MAXD : d.delay_depth;
     double *colv0 = sm_dyn, *nqv0 = colv0 + (size_t)depth * rpw, *lav = nqv0 + (size_t)depth * rpw,
            *rhsv = lav + rpw; // (nqv: what replaces a row's pivot-column entry, :25 / :36 -- one division per row and pivot, by one lane)
-    int *tlist = reinterpret_cast<int *>(rhsv + rpw), *tmask = tlist + (rpw + 3) / 4 * 4;
-    double *panel = rhsv + rpw + (rpw + 3) / 4 * 4; // (behind tlist and tmask, 16-byte aligned)
+    int *tlist = reinterpret_cast<int *>(rhsv + rpw), *tmask = tlist + (rpw + 3) / 4 * 4, *tpiv = tmask + (rpw + 3) / 4 * 4;
+    double *panel = rhsv + rpw + (rpw + 3) / 4 * 6; // (behind tlist, tmask and tpiv, 16-byte aligned)
     const double flushed = __longlong_as_double((long long)FLUSHED);
     // The pending normalised pivot rows: one scratch PER XCD (d.pend: [8 XCDs][2 sets][depth][pitch]).  Every workgroup computes the
     // same rows from the same published bytes; the workgroups of one XCD store them to the same place (identical values;
@@ -232,12 +232,13 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
             for (int base = 0; base < my_rows; base += 64) {
                 const int i = base + tl;
                 bool t = false;
-                int msk = 0; // bit p: pending pivot p touches the row (:31, or its pivot row); bit 16 + p: the row is p's pivot row
+                int msk = 0, pvm = 0; // bit p of msk: pending pivot p touches the row (:31, or its pivot row); of pvm: the row is p's pivot row
                 if (i < my_rows && b + i > 0) { // (not the objective row: the replica of it IS that row with every pending pivot applied)
 #pragma unroll 4
                     for (int p = 0; p < npend; p++) { // (no short circuit: the LDS reads of four pending pivots in flight, not a chain of round trips)
                         const int pv = i == sh_pl[p] ? 1 : 0, tc = (pv | (fabs(colv0[p * rpw + i]) > 1e-16 ? 1 : 0));
-                        msk |= (tc << p) | (pv << (16 + p));
+                        msk |= tc << p;
+                        pvm |= pv << p;
                     }
                     t = msk != 0;
                 }
@@ -246,6 +247,7 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
                     const int k = cnt + __popcll(m & ((1ull << tl) - 1ull));
                     tlist[k] = i;
                     tmask[k] = msk;
+                    tpiv[k] = pvm;
                 }
                 cnt += __popcll(m);
             }
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(T) void stream3_kernel(Desc d, int parity, int chun
             for (int j = 0; j < J; j++) row_st16<AUX_PLAIN>(rpk, lane_off + 16 * T * j, 0, ob[j]);
         }
         if constexpr (PANEL)
-            panel_flush<T, PU, 64, YALPS_PANEL_D, YALPS_PANEL_SETS, NT, 4, (J < 16 || CHECK)>(mat, pitch, b, NB, prow0, npend, colv0, nqv0, rpw, sh_pl, sh_pc, tlist, tmask, sh_nt, panel, rsrc_of YSTAMP_ARGS); // (4 loads of the fill in flight: with 8 hipcc spills loop invariants of the pivot loop in some instantiations; J < 16: the waves take their rows from a counter)
+            panel_flush<T, PU, 64, YALPS_PANEL_D, YALPS_PANEL_SETS, NT, 4, (J < 16)>(mat, pitch, b, NB, prow0, npend, colv0, nqv0, rpw, sh_pl, sh_pc, tlist, tmask, tpiv, sh_nt, panel, rsrc_of YSTAMP_ARGS); // (4 loads of the fill in flight: with 8 hipcc spills loop invariants of the pivot loop in some instantiations; J < 16: the waves take their rows from a counter)
         else // (few rows per workgroup: the pending rows straight from my XCD's scratch, round 2's form -- the panels' barriers and LDS
              // fills cost more than they save there: 1025 x 16385, 4 rows per workgroup, 32 -> 38 us per pivot with panels)
             direct_flush<T, J, (J >= 8 ? 2 : 3), NT, !(J == 16 && CHECK)>(mat, pitch, b, NB, prow0, npend, colv0, nqv0, rpw, sh_pl, sh_pc, tlist, sh_nt, rsrc_of);

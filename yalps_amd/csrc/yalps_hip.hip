@@ -823,22 +823,23 @@ static int32_t tableau_create_impl(yalps_ctx *ctx, int32_t width, int32_t hcap, 
             // 40.2 / 38.1; 17 rows -- 4097 x 16385 48.9 / 54.9, 4097^2 19.7 / 20.4; 20 rows -- 5001^2 24.8 / 28.2; beyond: panels only,
             // 6001^2 28.1, 8193^2 37.5, 16385^2 87.8 -- round 2: 33.4, 45.5, 141).
             const bool panel3 = env_int("YALPS_HIP_STREAM3_PANEL", rows_per_block >= STREAM3_PANEL_MIN_ROWS ? 1 : 0) != 0;
-            const int depth_default = panel3 ? STREAM3_DEFAULT_DEPTH_WIDE
+            const int depth_default = panel3 ? (sJ == 16 ? STREAM3_DEPTH_J16 : STREAM3_DEFAULT_DEPTH_WIDE)
                                              : sJ >= 8 ? (rows_per_block >= 8 ? 12 : 6) : std::min(8, std::max(4, (rows_per_block + 1) / 3)); // (2049 x 16385 from L2 at depth 8 / 12 / 16: 35.8 / 34.8 / 34.9 us per pivot)
             int depth3 = std::min(STREAM3_MAXD, std::max(2, env_int("YALPS_HIP_DELAY_DEPTH", depth_default)));
             auto lds3_of = [&](int dep) {
-                return sizeof(double) * (2 * (size_t)dep + 2) * (size_t)rows_per_block + 2 * sizeof(int32_t) * (((size_t)rows_per_block + 3) / 4 * 4) +
-                       (panel3 ? sizeof(double) * (size_t)dep * 2 * STREAM3_PANEL_UNITS : 0);
+                return sizeof(double) * (2 * (size_t)dep + 2) * (size_t)rows_per_block + 3 * sizeof(int32_t) * (((size_t)rows_per_block + 3) / 4 * 4) +
+                       (panel3 ? sizeof(double) * (size_t)dep * 2 * stream3_panel_units(sJ) : 0);
             };
-            while (depth3 > 2 && lds3_of(depth3) > 150 * 1024) depth3--;
+            const size_t lds3_cap = panel3 ? LDS_DYNAMIC_MAX : 150 * 1024; // (the panels take what the CU has: 160 KB less the kernel's static arrays)
+            while (depth3 > 2 && lds3_of(depth3) > lds3_cap) depth3--;
             const size_t lds3 = lds3_of(depth3);
             const int want_r = want_nt2 | (panel3 ? 2 : 0);
-            if (lds3 <= 150 * 1024)
+            if (lds3 <= lds3_cap)
                 for (const RVariant &v : kStream3)
                     if (v.T == 512 && v.J == sJ && v.R == want_r) t->svar2 = v;
             if (t->svar2.fn)
-                for (const RVariant &v : kStream3Check)
-                    if (v.T == 512 && v.J == sJ && v.R == want_r) t->svar2_check = v;
+                for (const RVariant &v : kStream3Check) // (checkCycles with rows of 16 units per lane: the form that sweeps straight from L2 -- with the panels it does not fit the registers; same LDS layout, the panel area unused)
+                    if (v.T == 512 && v.J == sJ && v.R == (sJ == 16 ? want_nt2 : want_r)) t->svar2_check = v;
             if (t->svar2.fn) {
                 t->sshmem2 = lds3;
                 d.delay_depth = depth3;
@@ -1966,7 +1967,7 @@ int32_t yalps_tableau_set_shard(yalps_tableau *t, int32_t rank, int32_t nranks, 
             const int depth_default = panel ? DSHARD_DEFAULT_DEPTH_PANEL : rows_per_block >= 8 ? 16 : DSHARD_DEFAULT_DEPTH;
             int depth = std::min(DSHARD_MAXD, std::max(2, env_int("YALPS_HIP_DELAY_DEPTH", depth_default)));
             auto lds_of = [&](int dep) {
-                return sizeof(double) * (2 * (size_t)dep + 2) * (size_t)rows_per_block + 2 * sizeof(int32_t) * (((size_t)rows_per_block + 3) / 4 * 4) +
+                return sizeof(double) * (2 * (size_t)dep + 2) * (size_t)rows_per_block + 3 * sizeof(int32_t) * (((size_t)rows_per_block + 3) / 4 * 4) +
                        (panel ? sizeof(double) * (size_t)dep * 2 * DSHARD_PANEL_UNITS : 0);
             };
             while (depth > 2 && lds_of(depth) > 150 * 1024) depth--;
