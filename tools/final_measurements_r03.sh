@@ -24,7 +24,7 @@ prof inplace_8193x8193 stream3_kernel -- python3 tools/profile_solve.py --size 8
 prof inplace_4097x16385 stream3_kernel -- python3 tools/profile_solve.py --size 16384 --rows 4096 --pivots 640
 prof inplace_1025x16385 stream3_kernel -- python3 tools/profile_solve.py --size 16384 --rows 1024 --pivots 1500
 echo "=== in place done"
-python3 tools/shape_sweep.py 32x32 128x128 256x256 512x512 1024x1024 1536x1536 2048x2048 2560x2560 3072x3072 3300x3000 4096x4096 5000x5000 512x4096 4096x512 1000x6000 10000x1000 11000x900 12000x1500 1024x8000 256x8192 8192x8192 1024x16384 2048x16384 4096x16384 1000x20000 > $out/shape_sweep.txt 2>&1
+python3 tools/shape_sweep.py 32x32 128x128 256x256 512x512 1024x1024 1536x1536 2048x2048 2560x2560 3072x3072 3300x3000 4096x4096 5000x5000 6000x6000 512x4096 4096x512 1000x6000 10000x1000 11000x900 12000x1500 1024x8000 256x8192 8192x8192 1024x16384 2048x16384 4096x16384 16384x16384 1000x20000 > $out/shape_sweep.txt 2>&1
 echo "=== shapes done"
 # row shards on one rank: the whole tableau and a rank's share of 2 / 4 / 8
 for rows in 0 8192 4096 2048; do

@@ -28,9 +28,14 @@ while time.time() < t_end:
         m[1::7, 0] = 0.0  # degenerate rows: ratios <= precision
     m[0, 0] = 0.0
     m = m.reshape(-1)
-    piv = float(rng.choice([1, 2, 3, 5, 9, 17, 40, 77]))
+    piv = float(rng.choice([1, 2, 3, 5, 9, 17, 40, 77, 131]))
     os.environ["YALPS_HIP_DELAY_KERNEL"] = str(rng.choice([2, 3, 3]))
-    os.environ["YALPS_HIP_DELAY_DEPTH"] = str(rng.integers(2, 9))
+    os.environ["YALPS_HIP_DELAY_DEPTH"] = str(rng.integers(2, 17))  # (round 3: up to 16 pending pivots)
+    panel = rng.choice(["", "0", "1"])  # the sweep through LDS panels / straight from L2: by rows per workgroup, or forced
+    if panel:
+        os.environ["YALPS_HIP_STREAM3_PANEL"] = str(panel)
+    else:
+        os.environ.pop("YALPS_HIP_STREAM3_PANEL", None)
     os.environ["YALPS_HIP_DELAY_NT"] = str(rng.integers(0, 2))
     pos = np.arange(w + h, dtype=np.int32); var = pos.copy()
     ref, rp, rv = m.copy(), pos.copy(), var.copy()
@@ -41,7 +46,7 @@ while time.time() < t_end:
     info = t.info()
     gm, gp, gv = t.download()
     t.close()
-    kinds[info["inplace"]] = kinds.get(info["inplace"], 0) + 1
+    kinds[info["inplace"] + "/" + info.get("sweep", "?")] = kinds.get(info["inplace"] + "/" + info.get("sweep", "?"), 0) + 1
     ok = (st, np_) == (est, epiv) and ((res != res and eres != eres) or res == eres) and \
         np.array_equal(gm.view(np.int64), ref.view(np.int64)) and np.array_equal(gp, rp) and np.array_equal(gv, rv)
     if not ok or info["last_path"] != "inplace":  # (stream2 where asked for and built, else stream3; sweep / stream_kernel below four rows per workgroup)
