@@ -84,6 +84,15 @@ def measured_traffic(size, resident, pivots_per_launch):
     workload and committed under profiles/ -- bench.py cannot run the profiler on itself."""
     name = "r02_pmc_traffic_resident.json" if resident else "r01_pmc_traffic.json"
     path = os.path.join(ROOT, "profiles", name)
+    if size in (16384, 8192):  # the delayed in-place kernel at BASELINE config 5 and at 8193^2: round 3's PMC passes (per pivot of a bounded launch)
+        name = "r03_pmc_traffic_delayed.json"
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            with open(path) as f:
+                for case in json.load(f)["cases"]:
+                    if case["tableau"] == "%dx%d" % (size + 1, size + 1):
+                        return case["traffic_bytes_per_pivot"] * pivots_per_launch, "profiles/" + name
+        return None, None
     if size != 2048 or not os.path.exists(path):
         return None, None
     with open(path) as f:
@@ -243,7 +252,7 @@ def main():
             us_launch = 1e3 * gpu_ms / (launches * args.steps)
             bytes_launch = bpp * npiv / launches
             ach = bytes_launch / (us_launch * 1e-6) / 1e9
-            traffic, traffic_source = (None, None) if inplace else measured_traffic(args.size, resident, bytes_launch / bpp)
+            traffic, traffic_source = measured_traffic(args.size, resident, bytes_launch / bpp) if (not inplace or args.size in (16384, 8192)) else (None, None)
             out["roofline"] = {
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
                 "frac_hbm": ach / HBM_PEAK_GBPS, "frac_of_copy_rate": ach / HBM_COPY_GBPS,

@@ -500,6 +500,39 @@ def test_inplace_path_matches_restatement(nat, ctx, monkeypatch, M, N, pivots, d
     assert np.array_equal(got.view(np.int64), ref.view(np.int64))
 
 
+@pytest.mark.parametrize("panel", ["1", "0"], ids=["panels", "from-L2"])
+@pytest.mark.parametrize("M,N,pivots", [(6000, 2060, 41), (3100, 4102, 37)])
+def test_sweep_tail_units_and_last_columns(nat, ctx, monkeypatch, oracle, M, N, pivots, panel):
+    """The sweep of the delayed kernels (panel_flush.cuh) takes the units behind the last full 1024-column panel through a routine
+    of their own (a lane per row and unit) -- rows of 2^k + 1 columns have one such unit.  Here the widths leave 8 and 4 tail units,
+    the objective makes the LAST columns enter first (the pivot-column patch, src/simplex.ts:25,36, lands in the tail; pending pivot
+    rows have flushed entries there, :17-24), one row starts infeasible: whole tableau, basis and status against the oracle."""
+    monkeypatch.setenv("YALPS_HIP_LDS_ROWS", "0")  # (99 and 102 MB: beyond the register files either way)
+    monkeypatch.setenv("YALPS_HIP_STREAM3_PANEL", panel)
+    w, h = N + 1, M + 1
+    m = nat.dense_lp(M, N, 23)
+    A = m.reshape(h, w)
+    A[0, w - 14:] *= 60.0          # Dantzig pricing (:71-79) takes the last columns first
+    A[h // 4] *= -1.0              # an infeasible start: phase 1 (:106-142)
+    A[3::5, w - 9::2] = 0.0        # exact zeros in the tail columns: flushed entries of pending pivot rows, untouched rows
+    pos, var = np.arange(w + h, dtype=np.int32), np.arange(w + h, dtype=np.int32)
+    ref, rpos, rvar = m.copy(), pos.copy(), var.copy()
+    est, eres, epiv, trace = oracle.simplex(ref, w, h, rpos, rvar, max_pivots=float(pivots), trace_cap=256)
+    assert (trace[:epiv, 1] >= w - 16).sum() >= 4, trace[:epiv]  # (the case does what it is for: pivot columns in the tail)
+    t = nat.DeviceTableau(ctx, w, h)
+    try:
+        t.upload(m, h, pos, var)
+        status, result, npiv, _ = t.solve(max_pivots=float(pivots))
+        info = t.info()
+        got, gpos, gvar = t.download()
+    finally:
+        t.close()
+    assert info["last_path"] == "inplace" and info["inplace"].startswith("stream3_kernel") and info["sweep"] == ("panels" if panel == "1" else "direct"), info
+    assert (status, npiv) == (est, epiv) and G.same_number(result, eres)
+    assert np.array_equal(gpos, rpos) and np.array_equal(gvar, rvar)
+    assert np.array_equal(got.view(np.int64), ref.view(np.int64))
+
+
 def test_inplace_path_sparse_netlib_whole_solve(nat, ctx, oracle):
     """SHIP12L (2197 x 5428, 95 MB, 0.4 % of the rows touched per pivot): the whole solve in place,
     every bit of the final tableau against the oracle."""
