@@ -3,7 +3,7 @@
 // one column PANEL at a time.
 // Part of libyalps_hip.so; included by persistent_stream3.hip / persistent_dshard.hip inside their unnamed namespaces.
 #pragma once
-#ifdef YALPS_STAMPS // (diagnostic build: the callers' stage sums continue inside the sweep, stages 11-17)
+#ifdef YALPS_STAMPS // (diagnostic build: the callers' stage sums continue inside the sweep, stages 11-18; tools/delayed_stages.py)
 #define YSTAMP_PARAMS , unsigned long long (&st_acc)[20], unsigned long long &st_last
 #define YSTAMP_ARGS , st_acc, st_last
 #else
@@ -19,6 +19,7 @@
 // workgroup and sweep, a pending entry costs one ds_read_b128 per D rows, and a lane holds one unit per row in flight, so
 // the sweep no longer decides the kernel's register budget (tools/micro/panel_sweep.hip, profiles/r03_panel_sweep.txt:
 // panels as wide as LDS allows; 16 pending pivots of 1024 columns = 128 KB; D rows in flight per lane).
+// What it took to make that fast, and what was tried and dropped: DESIGN.md 4.9b / 4.9c; the inner loop alone: tools/micro/lds_axpy.hip.
 //
 // The arithmetic per element is the reference's, pending pivot by pending pivot, oldest first (src/simplex.ts:14-38):
 //   the row that was pending pivot p's pivot row:  x = p-th normalised row (0.0 where pivot() flushed, :17-24)
@@ -50,7 +51,7 @@ __device__ __forceinline__ void panel_flush(double *mat, int pitch, int b, int N
     const int sub = tid / LU, lane = tid % LU;
     // A row of 2^k + 1 columns (every BASELINE configuration) is k' full panels and ONE more unit: a whole panel pass -- fill, two
     // barriers, every wave's trips through the pending pivots -- for 16 bytes of every row.  Up to TAIL units behind the last full
-    // panel go through tail_units() below instead: a lane per (row, unit), the pending rows' units straight from L2.
+    // panel go through the loop behind the panels instead: a lane per (row, unit), the pending rows' units straight from L2.
     constexpr int TAIL = 64;
     const int units = pitch >> 1, rem = units % PU, ntail = (units > PU && rem <= TAIL) ? rem : 0;
     const int npanel = (units - ntail + PU - 1) / PU;
@@ -244,7 +245,10 @@ __device__ __forceinline__ void panel_flush(double *mat, int pitch, int b, int N
                     rd_hdr(pnx, cfb);
                     rd_units(pnx, 0, pb);
                     __builtin_amdgcn_sched_barrier(0);
-                    work(p, cfa, 0, pa);
+                    if (is_plain)
+                        straight(cfa, 0, pa);
+                    else
+                        work(p, cfa, 0, pa);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int u = 0; u < UH; u++) pa[u] = pb[u];
@@ -264,6 +268,8 @@ __device__ __forceinline__ void panel_flush(double *mat, int pitch, int b, int N
         };
         // The waves of a workgroup TAKE their rows, D at a time, from a counter in LDS as they get free: with a fixed share a wave whose
         // loads came back late kept everybody waiting at the next panel's barrier (stage stamps at 16385^2: 15 % of a sweep).
+        // (ONE set of D rows in registers per wave: a second set -- the next trip's loads in flight under this trip's arithmetic -- was
+        // built twice, as whole rows and as half-segments, and gained nothing: DESIGN.md 4.9c.  SETS stays in the signature for the record.)
         static_assert(SETS == 1 && LU == 64, "a wave takes D rows per trip");
         // (DYN = false: the fixed share -- same box, alternating runs, us per pivot taken / fixed: 6001^2 25.7 / 26.5, 8193^2 32.8 / 32.95,
         // 4097^2 18.7 / 18.6, but 16385^2 79.7 / 76.8: the callers keep the fixed share for rows of 16 units per lane)
@@ -275,11 +281,10 @@ __device__ __forceinline__ void panel_flush(double *mat, int pitch, int b, int N
                 k0 = __builtin_amdgcn_readlane(k0, 0);
             }
             if (k0 >= nt) break; // (uniform)
-            double2 xa[D][U], xb[SETS == 2 ? D : 1][U];
-            int ria[D], rib[SETS == 2 ? D : 1], rma[D], rmb[SETS == 2 ? D : 1], rpa[D], rpb[SETS == 2 ? D : 1];
+            double2 xa[D][U];
+            int ria[D], rma[D], rpa[D];
             YSTAMP(12); // sweep: barrier behind the fill, flags / between trips
             load_set(k0, xa, ria, rma, rpa);
-            if constexpr (SETS == 2) load_set(k0 + RS * D, xb, rib, rmb, rpb);
 #ifdef YALPS_STAMPS
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -288,10 +293,6 @@ __device__ __forceinline__ void panel_flush(double *mat, int pitch, int b, int N
             YSTAMP(14); // sweep: the pending pivots applied in registers
             store_set(xa, ria);
             YSTAMP(15); // sweep: stores issued
-            if constexpr (SETS == 2) {
-                apply_set(xb, rib, rmb, rpb);
-                store_set(xb, rib);
-            }
         }
     }
     if (ntail > 0) { // (uniform)
