@@ -117,6 +117,11 @@ DELAYED = [
     ("hip-native", 2, 4700, 1000, 3, 90, False, {"YALPS_HIP_DELAY_DEPTH": "13", "YALPS_HIP_SHARD_PANEL": "1"}, "dshard_kernel<512,1,panel>,delay_depth:13"),
     ("hip", 2, 2300, 4200, 6, 150, False, {"YALPS_HIP_DELAY_DEPTH": "14"}, "dshard_kernel<512,6>,delay_depth:14"),
     ("hip-native", 2, 13000, 2100, 7, 45, True, {}, "dshard_kernel<512,4,panel>,delay_depth:16"),  # 26 rows per workgroup: the default
+    # the sweep as a launch of its own (dsweep_kernel.cuh: rows mapped to workgroups by panel and row block) is what the native loop
+    # takes below 24 rows per workgroup whenever a batch is a whole number of sweeps (the hip-native cases above with depths 8 and 2:
+    # batches of 8 pivots); here switched off for such a shard, and forced onto one with 26 rows per workgroup
+    ("hip-native", 3, 3300, 4200, 5, 131, True, {"YALPS_HIP_SHARD_XSWEEP": "0"}, "dshard_kernel<512,6>,delay_depth:8"),
+    ("hip-native", 2, 13000, 2100, 7, 45, True, {"YALPS_HIP_SHARD_XSWEEP": "1", "YALPS_HIP_DELAY_DEPTH": "8"}, "dshard_kernel<512,4,panel>,delay_depth:8"),
     # ... and the same shard one sweep per pivot, by request
     ("hip", 2, 2300, 4200, 6, 37, False, {"YALPS_HIP_SHARD_DELAY": "0"}, "wide_kernel<1024,4>"),
 ]

@@ -74,7 +74,7 @@ def kernel_metadata(lib=LIB):
 # Kernels whose rows / tableaux live in registers or LDS behind hand-written sc1 loads and stores: built without
 # scratch and without accumulator registers, or not at all.  (Two instantiations that broke this rule computed wrong
 # rows on the GPU -- DESIGN.md 4.7 -- so the rule is part of the build, not of an optional test.)
-NO_SCRATCH = ("dshard_kernel", "dshard_select_kernel", "small_kernel", "batch_kernel", "assemble", "resident_kernel", "resident2_kernel", "stream_kernel", "stream2_kernel", "stream3_kernel", "sweep_kernel")
+NO_SCRATCH = ("dshard_kernel", "dshard_select_kernel", "dshard_sweep_kernel", "small_kernel", "batch_kernel", "assemble", "resident_kernel", "resident2_kernel", "stream_kernel", "stream2_kernel", "stream3_kernel", "sweep_kernel")
 
 
 def check_register_budgets(lib=LIB, min_resident=15):

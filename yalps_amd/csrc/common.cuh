@@ -4,6 +4,7 @@
 
 
 constexpr int RUNNING = -1;
+constexpr int SHARD_SWEEP_MISSING = 77; // internal: a shard's step kernel found `depth` pivots still pending -- the sweep launch (dsweep_kernel.cuh) did not run; yalps_shard_run fails on it
 constexpr int MODE_FUSED = 0, MODE_DECIDE = 1, MODE_APPLY = 2, MODE_SHARD = 3;
 constexpr int SHARD_HDR = 8;  // doubles in front of the two candidate rows of a gather slot
 constexpr int MAX_SHARDS = 8; // one node of MI355X
@@ -136,6 +137,9 @@ struct Desc {
     // row shards with checkCycles: shard_cycle_kernel's verdict on the pivot the step launch of the same parity is about to
     // carry out ([2] by launch parity; 1 = hasCycle, src/simplex.ts:98,137)
     int32_t *cyc_verdict;
+    // row shards with delayed row updates: 1 = the step kernel leaves `delay_depth` pivots pending and the host enqueues
+    // dshard_sweep_kernel (dsweep_kernel.cuh) behind it; 0 = the step kernel sweeps its rows itself
+    int32_t ext_sweep;
     // diagnostic build only (-DYALPS_STAMPS, never the shipped library): [nb][STAMP_WORDS] per-workgroup stage sums in
     // shader cycles, written once when a persistent launch ends; no kernel reads it
     unsigned long long *dbg;

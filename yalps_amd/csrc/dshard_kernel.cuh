@@ -72,7 +72,7 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
     const double flushed = __longlong_as_double((long long)FLUSHED);
     double *const prow0 = d.dpend;
     int npend = Din->npend;
-    npend = npend < 0 ? 0 : npend > depth - 1 ? depth - 1 : npend; // (a launch starts with room for one more)
+    npend = npend < 0 ? 0 : npend > depth ? depth : npend; // (`depth` pending: the sweep of its own launch did not run -- swept below, before this pivot)
     const bool lav_valid = Din->lav_valid != 0;
 
     // basis bookkeeping of the pivot before this one (src/simplex.ts:7-12), as wide_kernel: its loads are this launch's oldest
@@ -322,6 +322,7 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
     const int check = C->check_cycles ? 1 : 0;
     if (term == RUNNING && check && d.cyc_verdict[parity & 1]) term = YALPS_CYCLED; // :98,137: shard_cycle_kernel's verdict on this pivot
     YSTAMP(1); // decide (the gathered records, phase 1: the entering column)
+    if (term == RUNNING && npend >= depth) term = SHARD_SWEEP_MISSING; // (a launch needs room for one more pending pivot: d.ext_sweep's launch did not run -- the host fails on this status)
     if (term != RUNNING) { // the solve ends here: the pending pivots are carried out on the way out
         flush_pending(objA);
         if (b == 0 && tid == 0) {
@@ -478,7 +479,8 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
     }
     YSTAMP(7); // my candidates, two arg-mins, the partials
     // ---------------- the rows: only every depth-th pivot ------------------------------------------------------------------
-    const int npend_out = npend == depth ? 0 : npend;
+    const bool ext = d.ext_sweep != 0; // the sweep is a launch of its own behind this one (dsweep_kernel.cuh): the pivots stay pending
+    const int npend_out = (npend == depth && !ext) ? 0 : npend;
     if (b == 0 && tid == 0) {
         write_state(RUNNING, phase, la, pbuf ^ 1, 1, row, col, (phase_switched ? 0 : hist_len_in) + check, iter + 1.0, NAN, pivots_in + 1);
         DelayState o = {};
@@ -491,7 +493,7 @@ __global__ __launch_bounds__(T) void dshard_kernel(Desc d, int parity, int /*mod
         *Dout = o;
     }
     YSTAMP(8); // state
-    if (npend == depth) flush_pending(objB);
+    if (npend == depth && !ext) flush_pending(objB);
     YSTAMP(9); // the sweep (every depth-th launch)
 #ifdef YALPS_STAMPS
     if (tid == 0 && d.dbg) {

@@ -42,6 +42,8 @@ PersistentTable yalps_stream3d_check_table();
 // const double *gather), launch-per-pivot like wide_kernel in MODE_SHARD; R = NT.  dshard_select_kernel: (Desc, int parity, double *send)
 PersistentTable yalps_dshard_table();
 const void *yalps_dshard_select_fn(int lanes); // lanes per workgroup: 1024, or 256 for shards of at most 256 workgroups
+// dshard_sweep_kernel<NT> (dsweep_kernel.cuh): the shard's sweep as a launch of its own, (Desc, int parity), 512 lanes, depth x 8 KB of LDS
+const void *yalps_dshard_sweep_fn(int nt);
 // exchange_floor_kernel<T, J>: the bare hand-off of the resident kernels, for bench.py's measured on-chip floor
 // (persistent_floor.hip): __global__ void (double *rows, unsigned long long *flags, int32_t *err, double *sink, int epochs, int variant)
 const void *yalps_exchange_floor_fn(int lanes, int units);

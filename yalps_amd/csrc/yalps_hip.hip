@@ -148,6 +148,7 @@ const std::vector<RVariant> kDshard = variants_of({yalps_dshard_table()}); // (l
 constexpr size_t SWEEP_BEYOND_CACHE = 200u << 20; // tableau bytes from which row traffic goes non-temporal (Infinity Cache: 256 MiB)
 constexpr int STREAM3_PANEL_MIN_ROWS = 12; // rows per workgroup from which stream3_kernel's sweep goes through LDS panels (panel_flush.cuh)
 constexpr int STREAM3_DEFAULT_DEPTH_WIDE = 16; // pending pivots of stream3_kernel for rows of 4098+ columns with 8+ rows per workgroup (YALPS_HIP_DELAY_DEPTH)
+constexpr int DSHARD_XSWEEP_BELOW_ROWS = 24;   // rows per workgroup below which a row shard's sweep is a launch of its own (dsweep_kernel.cuh)
 constexpr int DSHARD_PANEL_MIN_ROWS = 12;      // rows per workgroup from which a row shard's sweep goes through LDS panels (panel_flush.cuh)
 constexpr int DSHARD_DEFAULT_DEPTH_PANEL = 16; // ... and its pending pivots then
 constexpr int DSHARD_DEFAULT_DEPTH = 8; // pending pivots of a row shard (YALPS_HIP_DELAY_DEPTH, at most DSHARD_MAXD = 16)
@@ -360,6 +361,9 @@ struct yalps_tableau {
     int wT_inplace = 0;
     KernelFn dfn = nullptr;         // row shard with delayed row updates: dshard_kernel<512, dJ, nt> (d.dpend / dcolv / dnqv / dlav / dstate)
     int dJ = 0, dnt = 0, dpanel = 0;
+    const void *xsweep_fn = nullptr; // dshard_sweep_kernel: the shard's sweep as a launch of its own (dsweep_kernel.cuh)
+    int xsweep_grid = 0, shard_pend = 0; // its workgroups (panels x row blocks); pivots the host knows to be pending
+    size_t xsweep_lds = 0;
     size_t dshmem = 0;
     void *dsh_block = nullptr;      // ... its arrays, one allocation
     int32_t *cyc_block = nullptr;   // row shard: shard_cycle_kernel's verdict words (Desc::cyc_verdict)
@@ -985,7 +989,7 @@ int32_t yalps_tableau_info(const yalps_tableau *t, char *buf, int32_t len) {
     else
         std::snprintf(str, sizeof str, "pivot_kernel<%d,%d,%d>", t->var.T, t->var.J, t->var.R);
     std::snprintf(buf, (size_t)len, "streaming=%s workgroups=%d resident=%s inplace=%s giveups=%lld resident_off_for=%d inplace_off_for=%d "
-                  "last_path=%s last_resident_launches=%lld node_fused_runs=%lld lock_giveups=%lld decide=pivot_kernel<%d,%d,%d>", str,
+                  "last_path=%s last_resident_launches=%lld node_fused_runs=%lld lock_giveups=%lld decide=pivot_kernel<%d,%d,%d> shard_sweep=%s", str,
                   t->nb, res, inp, (long long)t->giveups, t->ctx->resident ? t->ctx->resident_skip : -1,
                   t->ctx->inplace ? t->ctx->inplace_skip : -1,
                   t->last_path == 1 ? "resident" : t->last_path == 2 ? "streaming" : t->last_path == 3 ? "resident+streaming"
@@ -993,7 +997,7 @@ int32_t yalps_tableau_info(const yalps_tableau *t, char *buf, int32_t len) {
                   : t->last_path == 9 ? "resident+inplace" : t->last_path == 11 ? "resident+inplace+streaming"
                   : t->last_path == 16 ? "generic" : "none",
                   (long long)(t->last_path & 9 ? t->last_launches : 0), (long long)t->node_fused_runs, (long long)t->ctx->lock_giveups,
-                  t->var.T, t->var.J, t->var.R); // (decide: the single-workgroup DECIDE launches of checkCycles on the launch-per-pivot path)
+                  t->var.T, t->var.J, t->var.R, !t->dfn ? "none" : t->d.ext_sweep ? "launch" : "inline"); // (decide: the single-workgroup DECIDE launches of checkCycles on the launch-per-pivot path)
     return 0;
 }
 
@@ -1946,6 +1950,7 @@ int32_t yalps_tableau_set_shard(yalps_tableau *t, int32_t rank, int32_t nranks, 
     // Delayed row updates (dshard_kernel.cuh): a pivot costs the shard its scalars, the sweep comes once per `depth` pivots.
     // Shards swept in place with at least YALPS_HIP_DELAY_MIN_ROWS rows per workgroup; YALPS_HIP_SHARD_DELAY=0: one sweep per pivot.
     t->dfn = nullptr;
+    t->xsweep_fn = nullptr;
     {
         const int rows_per_block = (d.hcap + t->nb - 1) / t->nb, units = d.pitch / 2;
         int dJ = 0;
@@ -1984,6 +1989,18 @@ int32_t yalps_tableau_set_shard(yalps_tableau *t, int32_t rank, int32_t nranks, 
                 t->dnt = nt ? 1 : 0;
                 t->dpanel = panel ? 1 : 0;
                 d.delay_depth = depth;
+                // the sweep as a launch of its own, rows mapped to workgroups by (panel, row block): one fill per workgroup, no barrier
+                // between its waves afterwards -- whatever the rows per workgroup of the step kernel (YALPS_HIP_SHARD_XSWEEP=0: the step kernel sweeps)
+                // Measured, one rank, 16385 columns, us per pivot with the sweep inside the step kernel / as its own launch: 2049 rows (8 per
+                // workgroup) 42.9 / 38.7, 4097 (16) 49.6 / 46.6, 8193 (32) 61.2 / 63.0, 16385 (64) 93.3 / 95.8 (the launch sweeps at 3.6-3.9 TB/s
+                // whatever the rows: its 32 coefficient reads per pair of rows are 32 cache lines 131 KB apart) -- hence below 24 rows per workgroup.
+                t->xsweep_fn = env_int("YALPS_HIP_SHARD_XSWEEP", rows_per_block < DSHARD_XSWEEP_BELOW_ROWS ? 1 : 0) ? yalps_dshard_sweep_fn(nt ? 1 : 0) : nullptr;
+                if (t->xsweep_fn) {
+                    const int npan = (d.pitch / 2 + DSHARD_PANEL_UNITS - 1) / DSHARD_PANEL_UNITS;
+                    t->xsweep_grid = npan * std::max(1, 256 / npan);
+                    t->xsweep_lds = sizeof(double) * 2 * DSHARD_PANEL_UNITS * (size_t)depth;
+                    if (int rc = allow_big_lds(t->ctx->device, t->xsweep_fn)) return rc;
+                }
                 if (t->dsh_block) HIP_TRY(hipFree(t->dsh_block));
                 t->dsh_block = nullptr;
                 const size_t hc = ((size_t)d.hcap + 1) / 2 * 2; // (16-byte parts)
@@ -2046,6 +2063,8 @@ int32_t yalps_shard_begin(yalps_tableau *t, double precision, double maxPivots, 
     HIP_TRY(hipGetLastError());
     t->shard_parity = 1;
     if (t->dfn) HIP_TRY(hipMemsetAsync(t->d.dstate, 0, 2 * sizeof(DelayState), t->ctx->stream)); // nothing pending
+    t->d.ext_sweep = 0; // (yalps_shard_run turns the sweep launch on: it knows the batch length)
+    t->shard_pend = 0;
     if (t->wfn_inplace) // (the scan left the tableau in buffer 1 and the partials in set 1: the first in-place launch reads replica 1)
         HIP_TRY(hipMemcpyAsync(t->d.obj[1], t->d.mat[1], sizeof(double) * (size_t)t->d.pitch, hipMemcpyDeviceToDevice, t->ctx->stream));
     return 0;
@@ -2262,6 +2281,11 @@ static int shard_step(yalps_tableau *t, yalps_comm *c, size_t slot) {
     }
     c->collectives++;
     launch_shard(t, c->recv);
+    if (t->d.ext_sweep && ++t->shard_pend == t->d.delay_depth) { // `depth` pivots pending behind this step: the sweep, a launch of its own
+        using SweepFn = void (*)(Desc, int);
+        reinterpret_cast<SweepFn>(const_cast<void *>(t->xsweep_fn))<<<dim3(t->xsweep_grid), dim3(512), t->xsweep_lds, t->ctx->stream>>>(t->d, t->shard_parity);
+        t->shard_pend = 0;
+    }
     t->shard_parity ^= 1;
     return 0;
 }
@@ -2280,6 +2304,8 @@ int32_t yalps_shard_run(yalps_tableau *t, yalps_comm *c, double precision, doubl
     if (check_every > SHARD_HIST_MARGIN / 2) check_every = (int32_t)(SHARD_HIST_MARGIN / 2);
     check_every &= ~1; // (even: the launch parity is back where it started after a batch, so one captured batch serves every replay)
     if (int rc = yalps_shard_begin(t, precision, maxPivots, checkCycles)) return rc;
+    // (the host counts the pending pivots: a batch has to end with none of them pending for one captured batch to serve every replay)
+    t->d.ext_sweep = (t->dfn && t->xsweep_fn && check_every % t->d.delay_depth == 0) ? 1 : 0;
     if (gpu_ms_out) HIP_TRY(hipEventRecord(ctx->ev0, s));
     // The first batch runs eagerly (RCCL sets its channels up on first use); from the second on the batch is ONE
     // hipGraph replay where the transport can be captured (RCCL's collectives can; the host transport waits per pivot).
@@ -2351,6 +2377,7 @@ int32_t yalps_shard_run(yalps_tableau *t, yalps_comm *c, double precision, doubl
         HIP_TRY(hipEventElapsedTime(gpu_ms_out, ctx->ev0, ctx->ev1));
     }
     t->cur = fin.mbuf;
+    if (fin.status == SHARD_SWEEP_MISSING) return fail(YALPS_E_DEVICE, "yalps_shard_run: a step kernel found the sweep launch missing (internal error)");
     if (status_out) *status_out = fin.status;
     if (result_out) *result_out = fin.result;
     if (pivots_out) *pivots_out = fin.pivots;
