@@ -1993,7 +1993,8 @@ int32_t yalps_tableau_set_shard(yalps_tableau *t, int32_t rank, int32_t nranks, 
                 // between its waves afterwards -- whatever the rows per workgroup of the step kernel (YALPS_HIP_SHARD_XSWEEP=0: the step kernel sweeps)
                 // Measured, one rank, 16385 columns, us per pivot with the sweep inside the step kernel / as its own launch: 2049 rows (8 per
                 // workgroup) 42.9 / 38.7, 4097 (16) 49.6 / 46.6, 8193 (32) 61.2 / 63.0, 16385 (64) 93.3 / 95.8 (the launch sweeps at 3.6-3.9 TB/s
-                // whatever the rows: its 32 coefficient reads per pair of rows are 32 cache lines 131 KB apart) -- hence below 24 rows per workgroup.
+                // whatever the rows; a row-major copy of the coefficients for it -- one cache line per row instead of 32 lines 131 KB apart per pair of
+                // rows -- changed nothing: 96.0 / 62.3 / 46.3 / 39.2) -- hence below 24 rows per workgroup.
                 t->xsweep_fn = env_int("YALPS_HIP_SHARD_XSWEEP", rows_per_block < DSHARD_XSWEEP_BELOW_ROWS ? 1 : 0) ? yalps_dshard_sweep_fn(nt ? 1 : 0) : nullptr;
                 if (t->xsweep_fn) {
                     const int npan = (d.pitch / 2 + DSHARD_PANEL_UNITS - 1) / DSHARD_PANEL_UNITS;
