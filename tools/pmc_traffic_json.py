@@ -43,18 +43,19 @@ for tag, rows in (("shard_2049x16385_prof", 2049), ("shard_16385x16385_prof", 16
     run = last_json(os.path.join(d, tag + ".json"))
     rd = wr = 0.0
     launches = 0
-    for sub in ("dshard_kernel", "dshard_select_kernel"):
+    for sub in ("dshard_kernel", "dshard_select_kernel", "dshard_sweep_kernel"):  # (the sweep kernel: one launch per `depth` pivots, its bytes spread over the pivots)
         f, n = pmc(tag, "FETCH_SIZE", sub + "<")
         w, _ = pmc(tag, "WRITE_SIZE", sub + "<")
         rd += 2.0 * f * 1024
         wr += w * 1024
-        launches = max(launches, n)
+        if sub != "dshard_sweep_kernel":
+            launches = max(launches, n)
     bpp = 16 * (rows - 1) * 16385 + 16 * 16385 + 8 * (rows - 1) + 8 * 16384 + 16 * (rows - 1)
     cases.append({"tableau": "%dx16385 (row shard, one rank)" % rows, "kernel": run["roofline"]["kernel"], "step_launches_profiled": launches,
                   "us_per_pivot_wall": run["roofline"]["us_per_pivot"], "algorithmic_bytes_per_pivot": bpp,
                   "read_bytes_per_pivot": rd / launches, "write_bytes_per_pivot": wr / launches, "traffic_bytes_per_pivot": (rd + wr) / launches,
                   "traffic_over_algorithmic": (rd + wr) / launches / bpp,
                   "hbm_TBps": (rd + wr) / launches / (run["roofline"]["us_per_pivot"] * 1e-6) / 1e12,
-                  "note": "select + step kernels; launches counted by the profiler include the warm-up pivots, the per-launch traffic does not depend on that"})
+                  "note": "select + step (+ sweep) kernels; launches counted by the profiler include the warm-up pivots, the per-launch traffic does not depend on that"})
 print(json.dumps({"what": "delayed-update kernels, round 3 (panel sweep, up to 16 pending pivots): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes "
                           "(tools/final_measurements_r03.sh); KB units; FETCH_SIZE doubled (gfx950, 16 B/lane reads); per pivot", "cases": cases}, indent=1))
