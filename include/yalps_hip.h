@@ -199,7 +199,9 @@ int32_t yalps_shard_poll(yalps_tableau *t, int32_t *status_out, double *result_o
  * host buffers (send_host: mine; recv_host: nranks slots in rank order; returns 0).
  * yalps_shard_run = yalps_shard_begin + { select, all-gather, apply } until the replicated status is final, the status
  * read back every `check_every` pivots; with RCCL the batch of check_every pivots is captured once into a hipGraph and
- * replayed.  Returns 0 or a negative error; *status_out / *result_out follow src/simplex.ts's return protocol and are
+ * replayed (a check_every that is a multiple of the shard's delay depth -- 16 or 8; 64 is -- lets shards with few rows per
+ * workgroup sweep their rows in a launch of their own, dsweep_kernel.cuh; any other value works, with the sweep inside the step
+ * kernel).  Returns 0 or a negative error; *status_out / *result_out follow src/simplex.ts's return protocol and are
  * identical on every rank. */
 typedef struct yalps_comm yalps_comm;
 typedef int32_t (*yalps_allgather_fn)(void *user, const double *send_host, double *recv_host, int64_t doubles_per_rank);
