@@ -542,6 +542,21 @@ __global__ __launch_bounds__(ST) void dshard_select_kernel(Desc d, int parity, d
     const int lr = cr.i == INT_MAX ? 0 : cr.i - d.row_base, ln = cn.i == INT_MAX ? 0 : cn.i - d.row_base;
     int npend = idle ? 0 : D->npend;
     npend = npend < 0 ? 0 : npend > MAXD ? MAXD : npend;
+    const int units = pitch / 2;
+    const double2 *r0 = reinterpret_cast<const double2 *>(mat + (size_t)lr * pitch), *r1 = reinterpret_cast<const double2 *>(mat + (size_t)ln * pitch);
+    double2 *o0 = reinterpret_cast<double2 *>(send + SHARD_HDR), *o1 = reinterpret_cast<double2 *>(send + SHARD_HDR + pitch);
+    // a lane's unit of a candidate row and of every pending row: issued BEFORE the candidates' scalars are fetched and published to the
+    // workgroup (neither depends on the other; behind the barrier they were one more memory round trip on every pivot's chain)
+    auto fetch = [&](int u, double2 &v, double2 (&pn)[MAXD]) __attribute__((always_inline)) {
+        const int which = u < units ? 0 : 1, uu = which ? u - units : u;
+        v = which ? r1[uu] : r0[uu];
+#pragma unroll
+        for (int p = 0; p < MAXD; p++)
+            pn[p] = p < npend ? reinterpret_cast<const double2 *>(d.dpend + (size_t)p * pitch)[uu] : make_double2(0.0, 0.0);
+    };
+    const int ufirst = blockIdx.x * ST + tid, ustride = gridDim.x * ST;
+    double2 v_first = make_double2(0.0, 0.0), pn_first[MAXD];
+    if (ufirst < 2 * units) fetch(ufirst, v_first, pn_first);
     if (tid < 2 * MAXD) {
         const int which = tid / MAXD, p = tid % MAXD, r = which ? ln : lr;
         if (p < npend) {
@@ -562,16 +577,8 @@ __global__ __launch_bounds__(ST) void dshard_select_kernel(Desc d, int parity, d
         send[6] = 0.0;
         send[7] = 0.0;
     }
-    const int units = pitch / 2;
-    const double2 *r0 = reinterpret_cast<const double2 *>(mat + (size_t)lr * pitch), *r1 = reinterpret_cast<const double2 *>(mat + (size_t)ln * pitch);
-    double2 *o0 = reinterpret_cast<double2 *>(send + SHARD_HDR), *o1 = reinterpret_cast<double2 *>(send + SHARD_HDR + pitch);
-    for (int u = blockIdx.x * ST + tid; u < 2 * units; u += gridDim.x * ST) {
+    auto finish = [&](int u, double2 v, const double2 (&pn)[MAXD]) __attribute__((always_inline)) {
         const int which = u < units ? 0 : 1, uu = which ? u - units : u;
-        double2 v = which ? r1[uu] : r0[uu];
-        double2 pn[MAXD];
-#pragma unroll
-        for (int p = 0; p < MAXD; p++)
-            pn[p] = p < npend ? reinterpret_cast<const double2 *>(d.dpend + (size_t)p * pitch)[uu] : make_double2(0.0, 0.0);
 #pragma unroll
         for (int p = 0; p < MAXD; p++) {
             if (p >= npend) continue;
@@ -601,5 +608,11 @@ __global__ __launch_bounds__(ST) void dshard_select_kernel(Desc d, int parity, d
             o1[uu] = v;
         else
             o0[uu] = v;
+    };
+    if (ufirst < 2 * units) finish(ufirst, v_first, pn_first);
+    for (int u = ufirst + ustride; u < 2 * units; u += ustride) {
+        double2 v, pn[MAXD];
+        fetch(u, v, pn);
+        finish(u, v, pn);
     }
 }
